@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (run ONLY in the build container, where /root/reference exists).
+
+    python tests/golden/make_golden.py [name ...]
+
+Runs the *unmodified* reference envs (imported through oracle/ref_harness.py) on small
+seeded synthetic panels and scripted/random action sequences, and stores inputs and
+outputs as compressed .npz fixtures next to this file.  The fixtures are data only
+(inputs + the reference's outputs); no reference source is stored.
+
+Oracle variants:
+  O-raw    : reference as shipped.  Used where every step's scaled integer actions are
+             distinct and non-zero, so np.argsort's tie order cannot matter.
+  O-stable : same module with its np.argsort defaulting to kind="stable" (harness-side
+             name substitution; reference files untouched).  Defines the canonical
+             order for tie-heavy and turbulence sequences.
+Each fixture records which variant produced it, the NumPy/pandas versions and the seed.
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_harness as rh  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- panels
+def synth_panel(seed, T, N, K, *, flag_frac=0.0, fp32_prices=True, price0=100.0):
+    """close [T,N], tech [T,K,N], risk [T] (all float64 values; fp32-representable
+    when fp32_prices so a float32 device copy is bit-identical input)."""
+    rng = np.random.default_rng(seed)
+    close = price0 * np.exp(np.cumsum(rng.normal(0, 0.01, (T, N)), axis=0))
+    tech = rng.normal(0, 1, (T, K, N))
+    risk = np.abs(rng.normal(0, 30, T))
+    if fp32_prices:
+        close = close.astype(np.float32).astype(np.float64)
+        tech = tech.astype(np.float32).astype(np.float64)
+        risk = risk.astype(np.float32).astype(np.float64)
+    if K:
+        tech[:, 0, :][tech[:, 0, :] == 1.0] = 0.5
+        if flag_frac > 0:  # plant the fork's "untradable" marker: first indicator == 1.0
+            tech[:, 0, :][rng.random((T, N)) < flag_frac] = 1.0
+    return close, tech, risk
+
+
+def tiefree_actions(rng, S, N, hmax):
+    """float32 actions whose (a*hmax).astype(int) are distinct and non-zero per step."""
+    pool = np.concatenate([np.arange(-hmax, 0), np.arange(1, hmax + 1)])
+    out = np.empty((S, N), dtype=np.float32)
+    for s in range(S):
+        k = rng.permutation(pool)[:N].astype(np.float64)
+        out[s] = ((k + 0.5 * np.sign(k)) / hmax).astype(np.float32)
+        got = (out[s] * hmax).astype(int)
+        assert np.array_equal(got, k.astype(int)), (got, k)
+    return out
+
+
+# ----------------------------------------------------------------- primary stock env
+def run_stock(name, *, seed, T, N, K, S, variant, actions="uniform", hmax=100,
+              initial_amount=1_000_000, shares0=None, buy_cost_pct=1e-3, sell_cost_pct=1e-3,
+              reward_scaling=1e-4, turbulence_threshold=None, flag_frac=0.0,
+              previous_state=False, store_obs=True, zero_frac=0.0, fp32_prices=True,
+              day0=0, reset_first=True):
+    mod = rh.load_stocktrading()
+    if variant == "O-stable":
+        rh.stable_argsort_patch(mod)
+    elif variant != "O-raw":
+        raise ValueError(variant)
+    rng = np.random.default_rng(seed + 1000)
+    close, tech, risk = synth_panel(seed, T, N, K, flag_frac=flag_frac, fp32_prices=fp32_prices)
+    names = [f"ind{k}" for k in range(K)]
+    df = rh.make_stock_frame(close, tech, risk, names, risk_col="turbulence")
+    if shares0 is None:
+        shares0 = [0] * N
+    shares0 = [int(x) for x in shares0]
+    kwargs = dict(df=df, stock_dim=N, hmax=hmax, initial_amount=initial_amount,
+                  num_stock_shares=list(shares0), buy_cost_pct=buy_cost_pct,
+                  sell_cost_pct=sell_cost_pct, reward_scaling=reward_scaling,
+                  state_space=1 + 2 * N + K * N, action_space=N, tech_indicator_list=names,
+                  turbulence_threshold=turbulence_threshold, risk_indicator_col="turbulence",
+                  print_verbosity=1, day=day0)
+    prev = None
+    if previous_state:
+        prev_cash = float(initial_amount) * 0.73
+        prev = [prev_cash] + close[0].tolist() + list(shares0) + [0.0] * (K * N)
+        kwargs.update(initial=False, previous_state=prev)
+    if actions == "uniform":
+        act = rng.uniform(-1, 1, (S, N)).astype(np.float32)
+        if zero_frac > 0:
+            act[rng.random((S, N)) < zero_frac] = 0.0
+    elif actions == "tiefree":
+        act = tiefree_actions(rng, S, N, hmax)
+    else:
+        raise ValueError(actions)
+
+    D = 1 + 2 * N + K * N
+    rec = dict(obs=[], reward=[], done=[], cash=[], shares=[], cost=[], trades=[],
+               turbulence=[], day=[], realised=[], reset_step=[], reset_obs=[],
+               term_asset_memory=[], term_step=[])
+    printed = io.StringIO()
+    cwd = os.getcwd()
+    os.makedirs("/tmp/golden_work/results", exist_ok=True)
+    os.chdir("/tmp/golden_work")
+    try:
+        with contextlib.redirect_stdout(printed):
+            env = mod.StockTradingEnv(**kwargs)
+            obs0 = np.asarray(env.state, dtype=np.float64)
+            if reset_first:   # what get_sb_env() does (env_stocktrading.py:549-552)
+                rec["reset_step"].append(-1)
+                rec["reset_obs"].append(np.asarray(env.reset(), dtype=np.float64))
+            for s in range(S):
+                a_in = act[s].copy()
+                n_act_before = len(env.actions_memory)
+                obs, rew, done, info = env.step(a_in)
+                rec["obs"].append(np.asarray(obs, dtype=np.float64))
+                rec["reward"].append(float(rew))
+                rec["done"].append(bool(done))
+                rec["cash"].append(float(env.state[0]))
+                rec["shares"].append(np.asarray(env.state[1 + N:1 + 2 * N], dtype=np.float64))
+                rec["cost"].append(float(env.cost))
+                rec["trades"].append(int(env.trades))
+                rec["turbulence"].append(float(env.turbulence))
+                rec["day"].append(int(env.day))
+                if len(env.actions_memory) > n_act_before:
+                    rec["realised"].append(np.asarray(env.actions_memory[-1], dtype=np.int64))
+                else:
+                    rec["realised"].append(np.zeros(N, dtype=np.int64))
+                if done:
+                    rec["term_step"].append(s)
+                    rec["term_asset_memory"].append(np.asarray(env.asset_memory, dtype=np.float64))
+                    rec["reset_step"].append(s)
+                    rec["reset_obs"].append(np.asarray(env.reset(), dtype=np.float64))
+    finally:
+        os.chdir(cwd)
+
+    shares = np.stack(rec["shares"])
+    assert np.array_equal(shares, np.round(shares)), "share counts must be integral"
+    out = dict(
+        # ---- inputs
+        close=close, tech=tech, risk=risk, actions=act,
+        cfg_int=np.array([T, N, K, S, hmax, int(turbulence_threshold is not None),
+                          int(not previous_state), day0, int(reset_first)], dtype=np.int64),
+        cfg_int_names=np.array(["T", "N", "K", "S", "hmax", "use_turbulence", "initial",
+                                "day0", "reset_first"]),
+        cfg_float=np.array([initial_amount if not previous_state else prev[0], buy_cost_pct,
+                            sell_cost_pct, reward_scaling,
+                            turbulence_threshold if turbulence_threshold is not None else 0.0,
+                            initial_amount], dtype=np.float64),
+        cfg_float_names=np.array(["cash0", "buy_cost_pct", "sell_cost_pct", "reward_scaling",
+                                  "turbulence_threshold", "ctor_initial_amount"]),
+        shares0=np.asarray(shares0, dtype=np.int64),
+        # ---- reference outputs
+        ctor_obs=obs0,
+        reward=np.asarray(rec["reward"]), done=np.asarray(rec["done"]),
+        cash=np.asarray(rec["cash"]), shares=shares.astype(np.int64),
+        cost=np.asarray(rec["cost"]), trades=np.asarray(rec["trades"], dtype=np.int64),
+        turbulence=np.asarray(rec["turbulence"]), day=np.asarray(rec["day"], dtype=np.int64),
+        realised=np.stack(rec["realised"]),
+        reset_step=np.asarray(rec["reset_step"], dtype=np.int64),
+        reset_obs=(np.stack(rec["reset_obs"]) if rec["reset_obs"] else np.zeros((0, D))),
+        term_step=np.asarray(rec["term_step"], dtype=np.int64),
+        printed=np.array(printed.getvalue()),
+        meta=np.array([f"variant={variant}", f"seed={seed}", f"numpy={np.__version__}",
+                       f"pandas={__import__('pandas').__version__}",
+                       "source=finrl/meta/env_stock_trading/env_stocktrading.py (unmodified)"]),
+    )
+    for j, am in enumerate(rec["term_asset_memory"]):
+        out[f"asset_memory_{j}"] = am
+    if store_obs:
+        out["obs"] = np.stack(rec["obs"])
+    path = os.path.join(HERE, f"stock_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB)  steps={S} "
+          f"episodes_done={len(rec['term_step'])} final_trades={rec['trades'][-1]}")
+    return out
+
+
+STOCK_SCENARIOS = {
+    # tie-free, unmodified reference; 2.5 episodes => stale-reset quirk exercised twice
+    "tiefree": dict(seed=11, T=24, N=30, K=8, S=60, variant="O-raw", actions="tiefree"),
+    # the same tie-free run through O-stable must be identical (checked by the tests)
+    "tiefree_stable": dict(seed=11, T=24, N=30, K=8, S=60, variant="O-stable", actions="tiefree"),
+    # DOW30 x 8 shape, uniform actions (ties are the norm), cash binds after ~40 steps
+    "ties": dict(seed=12, T=64, N=30, K=8, S=150, variant="O-stable", actions="uniform"),
+    # cash-bound from step 0, non-zero starting shares, asymmetric costs, planted
+    # untradable flags (first indicator == 1.0), different hmax / reward scaling
+    "cashbound": dict(seed=13, T=30, N=30, K=8, S=75, variant="O-stable", actions="uniform",
+                      hmax=50, initial_amount=50_000,
+                      shares0=np.random.default_rng(5).integers(0, 20, 30),
+                      buy_cost_pct=0.002, sell_cost_pct=0.0015, reward_scaling=1e-3,
+                      flag_frac=0.1, zero_frac=0.1),
+    # turbulence threshold: liquidation steps, buys suppressed, flag ignored when turbulent
+    "turbulence": dict(seed=14, T=48, N=30, K=8, S=120, variant="O-stable", actions="uniform",
+                       turbulence_threshold=40.0, flag_frac=0.05,
+                       shares0=np.random.default_rng(6).integers(0, 10, 30)),
+    # small ticker counts
+    "n2": dict(seed=15, T=20, N=2, K=3, S=50, variant="O-stable", actions="uniform",
+               initial_amount=20_000),
+    "n3_tiefree": dict(seed=16, T=20, N=3, K=1, S=50, variant="O-raw", actions="tiefree",
+                       initial_amount=30_000),
+    # ensemble carry-over path: initial=False, previous_state (env_stocktrading.py:423-450)
+    "prevstate": dict(seed=17, T=20, N=30, K=8, S=45, variant="O-stable", actions="uniform",
+                      previous_state=True, shares0=np.random.default_rng(7).integers(0, 30, 30),
+                      turbulence_threshold=60.0),
+    # prices NOT rounded to fp32 (real-data like); engine keeps close in fp64
+    "fp64prices": dict(seed=18, T=32, N=30, K=8, S=70, variant="O-stable", actions="uniform",
+                       fp32_prices=False, initial_amount=200_000),
+    # stepping straight after construction (no reset), from a non-zero start day
+    "noreset_day3": dict(seed=19, T=16, N=5, K=2, S=30, variant="O-stable", actions="uniform",
+                         day0=3, reset_first=False, initial_amount=10_000),
+    # longer run, scalars only (no per-step obs): 2+ episodes of 400 days, NASDAQ-ish width
+    "long": dict(seed=20, T=400, N=30, K=2, S=900, variant="O-stable", actions="uniform",
+                 store_obs=False, turbulence_threshold=75.0),
+}
+
+
+def main(argv):
+    names = argv or list(STOCK_SCENARIOS)
+    for n in names:
+        if n in STOCK_SCENARIOS:
+            run_stock(n, **STOCK_SCENARIOS[n])
+        else:
+            raise SystemExit(f"unknown scenario {n}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
