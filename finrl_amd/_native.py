@@ -1,0 +1,101 @@
+"""ctypes binding of libfinenv.so (include/finenv.h).  Fails loudly: no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfinenv.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+FINENV_OK = 0
+
+
+class NativeLibraryError(ImportError):
+    pass
+
+
+class FinenvError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC_DIR, "-s"] + (["-B"] if force else [])
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+class StockConfig(C.Structure):
+    _fields_ = [
+        ("n_envs", C.c_int32), ("n_tickers", C.c_int32), ("n_tech", C.c_int32),
+        ("n_days", C.c_int32), ("hmax", C.c_int32), ("use_turbulence", C.c_int32),
+        ("reset_quirk", C.c_int32), ("initial", C.c_int32), ("track_stats", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("buy_cost_pct", C.c_double), ("sell_cost_pct", C.c_double),
+        ("reward_scaling", C.c_double), ("turbulence_threshold", C.c_double),
+    ]
+
+
+class StockPanelPtrs(C.Structure):
+    _fields_ = [("close", C.c_void_p), ("obs_tmpl", C.c_void_p), ("untradable", C.c_void_p),
+                ("risk", C.c_void_p)]
+
+
+STOCK_STATE_FIELDS = ("cash", "holdings", "day", "price_day", "trades", "episode", "n_ret",
+                      "cost", "last_reward", "turbulence", "asset0", "prev_asset", "ret_mean",
+                      "ret_m2", "cash0", "shares0")
+
+
+class StockStatePtrs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in STOCK_STATE_FIELDS]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C finrl_amd/csrc` (needs hipcc). finrl_amd has no CPU "
+            "fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.finenv_abi_version.restype = C.c_int
+    L.finenv_strerror.restype = C.c_char_p
+    L.finenv_strerror.argtypes = [C.c_int]
+    L.finenv_device_count.restype = C.c_int
+    L.finenv_stock_create.argtypes = [C.POINTER(StockConfig), C.POINTER(C.c_void_p)]
+    L.finenv_stock_destroy.argtypes = [C.c_void_p]
+    L.finenv_stock_destroy.restype = None
+    L.finenv_stock_last_error.argtypes = [C.c_void_p]
+    L.finenv_stock_last_error.restype = C.c_char_p
+    L.finenv_stock_obs_dim.argtypes = [C.c_void_p]
+    L.finenv_stock_bind.argtypes = [C.c_void_p, C.POINTER(StockPanelPtrs),
+                                    C.POINTER(StockStatePtrs)]
+    L.finenv_stock_init.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    L.finenv_stock_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.finenv_stock_observe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.finenv_stock_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    L.finenv_stock_episode_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    if L.finenv_abi_version() != 1:
+        raise NativeLibraryError("libfinenv.so ABI version mismatch; rebuild")
+    _lib = L
+    return L
+
+
+def check(code: int, handle=None, what: str = ""):
+    if code == FINENV_OK:
+        return
+    L = lib()
+    msg = L.finenv_strerror(code).decode()
+    if handle:
+        detail = L.finenv_stock_last_error(handle).decode()
+        if detail:
+            msg = f"{msg}: {detail}"
+    raise FinenvError(f"{what or 'finenv'} failed ({code}): {msg}")

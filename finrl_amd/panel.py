@@ -1,0 +1,113 @@
+"""Panel packer: the DataFrame / arrays the reference env consumes -> the device-resident
+structure-of-arrays the HIP kernels read.
+
+Reference contracts followed:
+  * DataFrame form (env_stocktrading.py:64, :336 `df.loc[day]`): integer index = day
+    ordinal (finrl/meta/preprocessor/preprocessors.py:24-33 `data_split`), N rows per day in
+    ticker order, columns close / <tech names> / <risk col>.
+  * observation order (env_stocktrading.py:456-467): [cash | close[N] | shares[N] |
+    tech_0[N] | ... | tech_{K-1}[N]]  (indicator-major).
+
+Device layout (see include/finenv.h `finenv_stock_panel`):
+  close      f64 [T][N]   money arithmetic runs on the reference's own doubles
+  obs_tmpl   f32 [T][D]   ready-made observation rows (cash / holdings slots zero)
+  untradable u32 [T]      bit i <=> tech_0[t][i] == 1.0 evaluated in fp64 (:105, :174)
+  risk       f64 [T]
+The whole DOW30 x 8 x 2893-day panel is 4.2 MB: it stays resident in L2 / Infinity Cache,
+so per-step HBM traffic is the per-env state, actions and observations only.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class StockPanel:
+    def __init__(self, close, tech=None, risk=None, *, tech_names=None, dates=None,
+                 tickers=None):
+        close = np.ascontiguousarray(close, dtype=np.float64)
+        if close.ndim != 2:
+            raise ValueError("close must be [T, N]")
+        T, N = close.shape
+        if tech is None or np.size(tech) == 0:
+            tech = np.zeros((T, 0, N), dtype=np.float64)
+        tech = np.ascontiguousarray(tech, dtype=np.float64)
+        if tech.shape[0] != T or tech.shape[-1] != N or tech.ndim != 3:
+            raise ValueError(f"tech must be [T, K, N] = [{T}, K, {N}], got {tech.shape}")
+        risk = np.zeros(T) if risk is None else np.ascontiguousarray(risk, dtype=np.float64)
+        if risk.shape != (T,):
+            raise ValueError("risk must be [T]")
+        self.close, self.tech, self.risk = close, tech, risk
+        self.T, self.N, self.K = T, N, tech.shape[1]
+        self.D = 1 + 2 * N + self.K * N
+        self.tech_names = list(tech_names) if tech_names is not None else \
+            [f"tech{k}" for k in range(self.K)]
+        self.dates = list(dates) if dates is not None else list(range(T))
+        self.tickers = list(tickers) if tickers is not None else [f"TIC{i}" for i in range(N)]
+        self._device_cache = {}
+
+    # ------------------------------------------------------------------ constructors
+    @classmethod
+    def from_dataframe(cls, df, tech_indicator_list, risk_indicator_col="turbulence"):
+        """Pack the frame a reference StockTradingEnv would be given."""
+        idx = np.asarray(df.index)
+        days, inv = np.unique(idx, return_inverse=True)
+        T = len(days)
+        if len(df) % T:
+            raise ValueError("every day must hold the same number of tickers")
+        N = len(df) // T
+        order = np.argsort(inv, kind="stable")          # df.loc[day] keeps frame order
+        if not np.array_equal(np.bincount(inv, minlength=T), np.full(T, N)):
+            raise ValueError("every day must hold the same number of tickers")
+
+        def col(name):
+            return np.asarray(df[name], dtype=np.float64)[order].reshape(T, N)
+
+        close = col("close")
+        tech = np.stack([col(t) for t in tech_indicator_list], axis=1) if tech_indicator_list \
+            else np.zeros((T, 0, N))
+        if risk_indicator_col in df.columns:
+            risk = col(risk_indicator_col)[:, 0]        # .values[0], :341
+        else:
+            risk = np.zeros(T)
+        dates = np.asarray(df["date"])[order].reshape(T, N)[:, 0].tolist() \
+            if "date" in df.columns else list(range(T))
+        tickers = np.asarray(df["tic"])[order].reshape(T, N)[0].tolist() \
+            if "tic" in df.columns else None
+        return cls(close, tech, risk, tech_names=tech_indicator_list, dates=dates,
+                   tickers=tickers)
+
+    # ------------------------------------------------------------------ host packing
+    def obs_template(self) -> np.ndarray:
+        """f32 [T, D]: observation rows with cash / holdings slots left zero."""
+        T, N, K = self.T, self.N, self.K
+        out = np.zeros((T, self.D), dtype=np.float32)
+        out[:, 1:1 + N] = self.close.astype(np.float32)
+        out[:, 1 + 2 * N:] = self.tech.reshape(T, K * N).astype(np.float32)
+        return out
+
+    def untradable_bits(self) -> np.ndarray:
+        """u32 [T]: bit i set iff the first indicator of ticker i equals 1.0 (fp64 compare)."""
+        if self.N > 32:
+            raise ValueError("bitmask form supports N <= 32")
+        bits = np.zeros(self.T, dtype=np.uint32)
+        if self.K:
+            flag = self.tech[:, 0, :] == 1.0
+            w = (np.uint32(1) << np.arange(self.N, dtype=np.uint32))
+            bits = (flag * w[None, :]).sum(axis=1).astype(np.uint32)
+        return bits
+
+    def to_device(self, device):
+        """-> dict of torch tensors on `device` (cached per device)."""
+        import torch
+        key = str(device)
+        if key not in self._device_cache:
+            self._device_cache[key] = dict(
+                close=torch.from_numpy(self.close).to(device),
+                obs_tmpl=torch.from_numpy(self.obs_template()).to(device),
+                untradable=torch.from_numpy(self.untradable_bits().view(np.int32)).to(device),
+                risk=torch.from_numpy(self.risk).to(device),
+            )
+        return self._device_cache[key]
+
+    def nbytes_device(self):
+        return self.T * (8 * self.N + 4 * self.D + 4 + 8)

@@ -1,0 +1,276 @@
+"""Device-resident batch of StockTradingEnv instances (one HIP launch per step).
+
+``VecStockTradingEnv`` is tensor-in / tensor-out (the ElegantRL vectorised-env shape:
+``env_num, state_dim, action_dim, max_step, if_discrete, target_return``);
+``SB3VecEnvAdapter`` presents the same batch through the stable-baselines3 ``VecEnv``
+protocol (numpy in / numpy out, auto-reset with ``info["terminal_observation"]``), which is
+what the reference builds with ``DummyVecEnv([lambda: env])`` (env_stocktrading.py:549-552).
+
+All arithmetic happens in finrl_amd/csrc/finenv_stock.hip through the C ABI; this module
+only owns the torch tensors that back the state and hands their pointers over.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as nat
+from .panel import StockPanel
+from .spaces import Box
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class VecStockTradingEnv:
+    """E parallel copies of the reference ``StockTradingEnv`` (env_stocktrading.py:19-552).
+
+    Constructor keywords keep the reference's names (``hmax, initial_amount,
+    num_stock_shares, buy_cost_pct, sell_cost_pct, reward_scaling, turbulence_threshold,
+    day, initial``).  ``initial_amount`` / ``num_stock_shares`` may be per-env
+    ([E] / [E, N]) which also covers the ``previous_state`` carry-over (:423-450).
+    Costs are scalars, as in this fork (:118, :179).
+    """
+
+    if_discrete = False
+    env_name = "StockTradingEnv-MI355X"
+    target_return = 10.0
+
+    def __init__(self, panel: StockPanel, num_envs: int, *, hmax=100,
+                 initial_amount=1_000_000, num_stock_shares=None, buy_cost_pct=1e-3,
+                 sell_cost_pct=1e-3, reward_scaling=1e-4, turbulence_threshold=None,
+                 day=0, initial=True, reset_quirk=True, track_stats=True, auto_reset=True,
+                 device="cuda"):
+        torch = _torch()
+        if not isinstance(buy_cost_pct, (int, float)) or not isinstance(sell_cost_pct, (int, float)):
+            # the fork's own env raises TypeError on list costs
+            raise TypeError("buy_cost_pct / sell_cost_pct must be scalars in this fork")
+        self.panel = panel
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise nat.FinenvError("finrl_amd has no CPU path: device must be a HIP GPU")
+        E, N, K, T = int(num_envs), panel.N, panel.K, panel.T
+        self.num_envs = self.env_num = E
+        self.stock_dim = self.action_dim = N
+        self.state_dim = self.state_space = panel.D
+        self.max_step = T - 1
+        self.hmax = int(hmax)
+        self.reward_scaling = float(reward_scaling)
+        self.turbulence_threshold = turbulence_threshold
+        self.auto_reset = bool(auto_reset)
+        self.observation_space = Box(-np.inf, np.inf, (panel.D,), np.float32)
+        self.action_space = Box(-1.0, 1.0, (N,), np.float32)
+
+        self._cfg = nat.StockConfig(
+            E, N, K, T, self.hmax, int(turbulence_threshold is not None), int(bool(reset_quirk)),
+            int(bool(initial)), int(bool(track_stats)), 0, float(buy_cost_pct),
+            float(sell_cost_pct), float(reward_scaling),
+            float(turbulence_threshold) if turbulence_threshold is not None else 0.0)
+        L = nat.lib()
+        self._h = C.c_void_p()
+        nat.check(L.finenv_stock_create(C.byref(self._cfg), C.byref(self._h)), None,
+                  "finenv_stock_create")
+
+        dev = self.device
+        f64 = dict(dtype=torch.float64, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        cash0 = np.broadcast_to(np.asarray(initial_amount, dtype=np.float64), (E,))
+        if num_stock_shares is None:
+            num_stock_shares = np.zeros(N, dtype=np.int64)
+        sh0 = np.broadcast_to(np.asarray(num_stock_shares, dtype=np.int64), (E, N))
+        self.state = dict(
+            cash=torch.zeros(E, **f64), holdings=torch.zeros(N, E, **i32),
+            day=torch.zeros(E, **i32), price_day=torch.zeros(E, **i32),
+            trades=torch.zeros(E, **i32), episode=torch.zeros(E, **i32),
+            n_ret=torch.zeros(E, **i32), cost=torch.zeros(E, **f64),
+            last_reward=torch.zeros(E, **f64), turbulence=torch.zeros(E, **f64),
+            asset0=torch.zeros(E, **f64), prev_asset=torch.zeros(E, **f64),
+            ret_mean=torch.zeros(E, **f64), ret_m2=torch.zeros(E, **f64),
+            cash0=torch.from_numpy(np.ascontiguousarray(cash0)).to(dev),
+            shares0=torch.from_numpy(np.ascontiguousarray(sh0.T).astype(np.int32)).to(dev),
+        )
+        self._panel_t = panel.to_device(dev)
+        pp = nat.StockPanelPtrs(*(self._panel_t[k].data_ptr()
+                                  for k in ("close", "obs_tmpl", "untradable", "risk")))
+        sp = nat.StockStatePtrs(*(self.state[k].data_ptr() for k in nat.STOCK_STATE_FIELDS))
+        nat.check(L.finenv_stock_bind(self._h, C.byref(pp), C.byref(sp)), self._h, "bind")
+
+        self.obs = torch.zeros(E, panel.D, dtype=torch.float32, device=dev)
+        self.reward = torch.zeros(E, dtype=torch.float32, device=dev)
+        self.done = torch.zeros(E, dtype=torch.uint8, device=dev)
+        self.term_obs = None
+        self.realised = None
+        self._stats = None
+        nat.check(L.finenv_stock_init(self._h, int(day), self._stream()), self._h, "init")
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        torch = _torch()
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                nat.lib().finenv_stock_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    close = __del__
+
+    def enable_terminal_obs(self):
+        torch = _torch()
+        if self.term_obs is None:
+            self.term_obs = torch.zeros_like(self.obs)
+        return self.term_obs
+
+    def enable_realised(self):
+        torch = _torch()
+        if self.realised is None:
+            self.realised = torch.zeros(self.num_envs, self.stock_dim, dtype=torch.int32,
+                                        device=self.device)
+        return self.realised
+
+    # ------------------------------------------------------------------ env protocol
+    def reset(self, mask=None):
+        """reset() (:359-393) for all envs (or mask[e] != 0) -> obs [E, D] f32 (device)."""
+        L = nat.lib()
+        mptr = None
+        if mask is not None:
+            torch = _torch()
+            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            mptr = C.c_void_p(mask.data_ptr())
+        nat.check(L.finenv_stock_reset(self._h, mptr, C.c_void_p(self.obs.data_ptr()),
+                                       self._stream()), self._h, "reset")
+        return self.obs
+
+    def observe(self):
+        """render() (:395-396): current observation without stepping."""
+        nat.check(nat.lib().finenv_stock_observe(self._h, C.c_void_p(self.obs.data_ptr()),
+                                                 self._stream()), self._h, "observe")
+        return self.obs
+
+    def step(self, actions):
+        """One step() (:220-357) for every env, asynchronously on the current stream.
+
+        actions: float32 [E, N] CUDA tensor.  Returns (obs, reward, done, info) where the
+        first three are views of persistent device tensors, overwritten by the next call
+        (clone them to keep).  No host synchronisation happens here.
+        """
+        torch = _torch()
+        if actions.dtype != torch.float32 or not actions.is_contiguous() or \
+                actions.device != self.obs.device or \
+                tuple(actions.shape) != (self.num_envs, self.stock_dim):
+            actions = actions.to(device=self.device, dtype=torch.float32).reshape(
+                self.num_envs, self.stock_dim).contiguous()
+        L = nat.lib()
+        nat.check(L.finenv_stock_step(
+            self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(self.obs.data_ptr()),
+            C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr()),
+            C.c_void_p(self.term_obs.data_ptr()) if self.term_obs is not None else None,
+            C.c_void_p(self.realised.data_ptr()) if self.realised is not None else None,
+            int(self.auto_reset), self._stream()), self._h, "step")
+        return self.obs, self.reward, self.done, None
+
+    # ------------------------------------------------------------------ introspection
+    def episode_stats(self):
+        """Terminal-branch summary (:226-264) -> f64 [E, 6] device tensor:
+        begin_total_asset, end_total_asset, total_reward, total_cost, total_trades, sharpe."""
+        torch = _torch()
+        if self._stats is None:
+            self._stats = torch.zeros(self.num_envs, 6, dtype=torch.float64, device=self.device)
+        nat.check(nat.lib().finenv_stock_episode_stats(
+            self._h, C.c_void_p(self._stats.data_ptr()), self._stream()), self._h, "stats")
+        return self._stats
+
+    def total_asset(self):
+        return self.episode_stats()[:, 1]
+
+    def episode_return(self):
+        """end_total_asset / begin_total_asset per env (the quantity gathered across ranks)."""
+        st = self.episode_stats()
+        return (st[:, 1] / st[:, 0]).to(_torch().float32)
+
+    def state_numpy(self):
+        """Host copy of the per-env state (synchronises)."""
+        out = {k: v.detach().cpu().numpy() for k, v in self.state.items()}
+        out["shares"] = np.ascontiguousarray(out.pop("holdings").T)
+        out["shares0"] = np.ascontiguousarray(out["shares0"].T)
+        return out
+
+    def as_sb3_vec_env(self):
+        return SB3VecEnvAdapter(self)
+
+
+class SB3VecEnvAdapter:
+    """stable-baselines3 ``VecEnv``-shaped view of a VecStockTradingEnv.
+
+    SB3 itself is not vendored in the reference (setup.py:34-36) nor installed here, so this
+    follows its documented public behaviour: ``reset() -> float32 [E, D]``;
+    ``step_wait() -> (obs f32 [E, D], rewards f32 [E], dones bool [E], infos list[dict])``
+    with auto-reset and ``infos[i]["terminal_observation"]``.
+    """
+
+    def __init__(self, env: VecStockTradingEnv):
+        self.env = env
+        env.auto_reset = True
+        env.enable_terminal_obs()
+        self.num_envs = env.num_envs
+        self.observation_space = env.observation_space
+        self.action_space = env.action_space
+        self._actions = None
+        self.render_mode = None
+
+    def reset(self):
+        return self.env.reset().cpu().numpy()
+
+    def step_async(self, actions):
+        self._actions = actions
+
+    def step_wait(self):
+        torch = _torch()
+        a = self._actions
+        if not torch.is_tensor(a):
+            a = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+        a = a.to(self.env.device, non_blocking=True)
+        obs, rew, done, _ = self.env.step(a)
+        obs_h = obs.cpu().numpy()
+        rew_h = rew.cpu().numpy()
+        done_h = done.cpu().numpy().astype(bool)
+        infos = [{} for _ in range(self.num_envs)]
+        if done_h.any():
+            idx = np.nonzero(done_h)[0]
+            term = self.env.term_obs[torch.from_numpy(idx).to(self.env.device)].cpu().numpy()
+            for j, i in enumerate(idx):
+                infos[i]["terminal_observation"] = term[j]
+        return obs_h, rew_h, done_h, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self):
+        pass
+
+    def seed(self, seed=None):
+        return [seed] * self.num_envs
+
+    def render(self, mode="human"):
+        return self.env.observe().cpu().numpy()
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False] * self.num_envs
+
+    def get_attr(self, name, indices=None):
+        v = getattr(self.env, name)
+        return [v] * self.num_envs
+
+    def set_attr(self, name, value, indices=None):
+        setattr(self.env, name, value)
+
+    def env_method(self, name, *args, indices=None, **kwargs):
+        r = getattr(self.env, name)(*args, **kwargs)
+        return [r] * self.num_envs

@@ -1,0 +1,165 @@
+/*
+ * finenv.h -- C ABI of libfinenv.so: MI355X-native batched trading environments.
+ *
+ * This is the drop-in boundary for the reference's market-environment hot path
+ * (superyuri/FinRL, finrl/meta/env_stock_trading/env_stocktrading.py).  The reference
+ * is pure Python, so there is no existing FFI to mirror symbol-for-symbol; each entry
+ * point below names the reference method (file:line) whose work it replaces, and
+ * INTEGRATION.md shows the ctypes binding a FinRL maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / C++ types cross the boundary.
+ *   - Every buffer is CALLER-OWNED DEVICE memory (e.g. torch tensor .data_ptr());
+ *     the library allocates nothing on the device and never synchronises the stream.
+ *   - All launches go to the caller's hipStream_t, passed as void* (0 = null stream).
+ *   - Return value: 0 = FINENV_OK, negative = error (finenv_strerror /
+ *     finenv_stock_last_error).  No exceptions cross the ABI.
+ *   - One handle per (device, stream) user; handles are thread-compatible, not
+ *     thread-safe.
+ *   - There is NO CPU fallback: without a HIP device every launch entry point fails
+ *     with FINENV_ERR_HIP.
+ *
+ * Layout (E envs, N tickers, K indicators, T days, D = 1 + 2N + K*N)
+ *   actions  [E][N] f32 row-major  (what SB3 / ElegantRL hand over)
+ *   obs      [E][D] f32 row-major  = [cash | close[N] | holdings[N] | tech[K][N]]
+ *                                    (indicator-major, env_stocktrading.py:456-467)
+ *   state    structure-of-arrays over envs; holdings is [N][E] (ticker-major) so that
+ *            lane e of a wavefront reads holdings[i][e] coalesced.
+ */
+#ifndef FINENV_H
+#define FINENV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FINENV_ABI_VERSION 1
+
+enum {
+    FINENV_OK = 0,
+    FINENV_ERR_INVALID = -1,     /* bad argument / unsupported shape            */
+    FINENV_ERR_UNBOUND = -2,     /* panel or state not bound yet                */
+    FINENV_ERR_HIP = -3,         /* HIP runtime error (see *_last_error)        */
+    FINENV_ERR_NOMEM = -4
+};
+
+#define FINENV_STOCK_MAX_TICKERS 32   /* lane-per-env kernel: N <= 32 (DOW30)   */
+
+/* Constructor arguments of StockTradingEnv that shape the arithmetic
+ * (env_stocktrading.py:24-47). */
+typedef struct finenv_stock_config {
+    int32_t n_envs;               /* E                                                   */
+    int32_t n_tickers;            /* stock_dim, :50                                      */
+    int32_t n_tech;               /* len(tech_indicator_list), :59                       */
+    int32_t n_days;               /* len(df.index.unique()), :221                        */
+    int32_t hmax;                 /* :51; |action*hmax| must stay below 2^25             */
+    int32_t use_turbulence;       /* turbulence_threshold is not None, :68               */
+    int32_t reset_quirk;          /* 1: reset() builds obs from the row held before the
+                                     rewind (reference behaviour, :361 vs :380-381)      */
+    int32_t initial;              /* `initial` flag, :70 -- selects the summation order
+                                     of asset_memory[0] (:364-378)                       */
+    int32_t track_stats;          /* keep running mean/M2 of daily returns (Sharpe,
+                                     :243-251) on device                                 */
+    int32_t reserved0;
+    double  buy_cost_pct;         /* scalar in this fork, :54                            */
+    double  sell_cost_pct;        /* :55                                                 */
+    double  reward_scaling;       /* :56                                                 */
+    double  turbulence_threshold; /* :68                                                 */
+} finenv_stock_config;
+
+/* Read-only market panel (device pointers), packed by finrl_amd.panel.StockPanel from
+ * the DataFrame the reference env receives (index = day ordinal, rows sorted by
+ * (date, tic): preprocessors.py:24-33). */
+typedef struct finenv_stock_panel {
+    const double   *close;        /* [T][N]  fp64 closes: the money arithmetic runs on
+                                     the same doubles the reference holds in state[1..N] */
+    const float    *obs_tmpl;     /* [T][D]  f32 observation rows with the cash and
+                                     holdings slots zero: f32(close) and f32(tech) in obs
+                                     order (what DummyVecEnv's float32 buffer would hold) */
+    const uint32_t *untradable;   /* [T]     bit i set <=> first indicator of ticker i
+                                     == 1.0 on that day (the fork's `!= True` test,
+                                     :105, :174), evaluated on the fp64 values           */
+    const double   *risk;         /* [T]     df[risk_indicator_col], :337-341 (may be
+                                     NULL when use_turbulence == 0)                      */
+} finenv_stock_panel;
+
+/* Mutable per-env state (device pointers, all caller-owned). */
+typedef struct finenv_stock_state {
+    double  *cash;                /* [E]     state[0]                                    */
+    int32_t *holdings;            /* [N][E]  state[1+N .. 1+2N)                          */
+    int32_t *day;                 /* [E]     self.day                                    */
+    int32_t *price_day;           /* [E]     row whose prices/indicators sit in the
+                                             current observation (== day except right
+                                             after a quirk reset)                        */
+    int32_t *trades;              /* [E]     self.trades                                 */
+    int32_t *episode;             /* [E]     self.episode                                */
+    int32_t *n_ret;               /* [E]     number of daily returns accumulated         */
+    double  *cost;                /* [E]     self.cost                                   */
+    double  *last_reward;         /* [E]     self.reward (scaled; survives reset)        */
+    double  *turbulence;          /* [E]     self.turbulence                             */
+    double  *asset0;              /* [E]     asset_memory[0]                             */
+    double  *prev_asset;          /* [E]     asset_memory[-1]                            */
+    double  *ret_mean;            /* [E]     Welford mean of pct_change(asset_memory)    */
+    double  *ret_m2;              /* [E]     Welford M2                                  */
+    const double  *cash0;         /* [E]     initial_amount / previous_state[0]          */
+    const int32_t *shares0;       /* [N][E]  num_stock_shares / previous_state shares    */
+} finenv_stock_state;
+
+typedef struct finenv_stock finenv_stock;   /* opaque host-side handle */
+
+int         finenv_abi_version(void);
+const char *finenv_strerror(int code);
+/* Number of HIP devices visible, or a negative FINENV_ERR_HIP. */
+int         finenv_device_count(void);
+
+/* StockTradingEnv.__init__ (:24-100), config part.  Validates shapes. */
+int  finenv_stock_create(const finenv_stock_config *cfg, finenv_stock **out);
+void finenv_stock_destroy(finenv_stock *h);
+const char *finenv_stock_last_error(const finenv_stock *h);
+int  finenv_stock_obs_dim(const finenv_stock *h);
+
+/* Attach the panel and state buffers (replaces self.df / self.state ownership). */
+int finenv_stock_bind(finenv_stock *h, const finenv_stock_panel *panel,
+                      const finenv_stock_state *state);
+
+/* __init__ state part (:64-91): every env starts on `day0` with cash0/shares0,
+ * turbulence = cost = trades = episode = 0; no observation is produced
+ * (use finenv_stock_observe). */
+int finenv_stock_init(finenv_stock *h, int32_t day0, void *stream);
+
+/* reset() (:359-393) for all envs, or those with mask[e] != 0 (device u8[E], may be
+ * NULL).  Writes the reset observation rows into obs_out [E][D] (rows of unmasked envs
+ * are left untouched). */
+int finenv_stock_reset(finenv_stock *h, const uint8_t *mask, float *obs_out, void *stream);
+
+/* render() / current state (:395-396): writes obs [E][D] without changing state. */
+int finenv_stock_observe(finenv_stock *h, float *obs_out, void *stream);
+
+/* step() (:220-357) for all envs in ONE launch.
+ *   actions   [E][N] f32 in [-1, 1]
+ *   obs       [E][D] f32 (next observation; after auto-reset: the reset observation)
+ *   reward    [E]    f32 (float32 cast of the fp64 reward, as DummyVecEnv stores it)
+ *   done      [E]    u8
+ *   term_obs  [E][D] f32 or NULL: rows of envs with done == 1 receive the terminal
+ *             observation (SB3 info["terminal_observation"]); other rows untouched
+ *   realised  [E][N] i32 or NULL: shares actually traded (the values the reference
+ *             writes back into `actions`, :324/:330 -> actions_memory)
+ *   auto_reset != 0: envs that report done are reset inside the same launch
+ *             (SB3 DummyVecEnv.step_wait semantics); 0: plain gym semantics (state
+ *             unchanged on the terminal step, :301).
+ */
+int finenv_stock_step(finenv_stock *h, const float *actions, float *obs, float *reward,
+                      uint8_t *done, float *term_obs, int32_t *realised, int32_t auto_reset,
+                      void *stream);
+
+/* Terminal-branch summary (:226-264) for every env, computed from current state:
+ * out [E][6] f64 = {begin_total_asset, end_total_asset, total_reward, total_cost,
+ *                   total_trades, sharpe (NaN if undefined)}. */
+int finenv_stock_episode_stats(finenv_stock *h, double *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FINENV_H */
