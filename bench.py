@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the batched StockTradingEnv hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched as
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per
+GPU, RCCL).  Prints ONE JSON line on rank 0.
+
+Workload = BASELINE.json configs[1]: 65,536 vectorised StockTradingEnv per GPU, DOW30 x 8
+indicators, T = 2893 days (Stock_NeurIPS2018 split), uniform(-1,1) random actions, synthetic
+panel.  A "step" is ONE launch of the step kernel over the whole batch
+(E env-steps), including the terminal/auto-reset step of every episode.  Inputs (panel,
+state, a pool of pre-generated action batches) are resident in HBM before the timed region.
+
+N > 1: independent env shards per rank (weak scaling), no data-path collective; the only
+collective is the RCCL all_gather of per-env episode returns at each episode end
+(SURVEY.md 8e), inside the timed region.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+E_PER_GPU = 65_536
+N_TICKERS, N_TECH, N_DAYS = 30, 8, 2893
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def algorithmic_bytes(N, K):
+    """actions 4N + state read (12+4N) + state write (12+4N) + obs write
+    4(1+2N+KN) + reward 4 + done 1  ==  4KN + 20N + 33  (1593 B at N=30, K=8)."""
+    return 4 * K * N + 20 * N + 33
+
+
+def synth_panel(T=N_DAYS, N=N_TICKERS, K=N_TECH, seed=0):
+    """close = f32(100*exp(cumsum N(0, 0.01^2))), tech = f32(N(0,1)) with no
+    exact 1.0 in indicator 0, risk = f32(|N(0,30)|); default_rng(0)."""
+    rng = np.random.default_rng(seed)
+    close = (100 * np.exp(np.cumsum(rng.normal(0, 0.01, (T, N)), axis=0))).astype(np.float32)
+    tech = rng.normal(0, 1, (T, K, N)).astype(np.float32)
+    tech[:, 0, :][tech[:, 0, :] == 1.0] = 0.5
+    risk = np.abs(rng.normal(0, 30, T)).astype(np.float32)
+    return close.astype(np.float64), tech.astype(np.float64), risk.astype(np.float64)
+
+
+ENV_KW = dict(hmax=100, initial_amount=1_000_000, buy_cost_pct=1e-3, sell_cost_pct=1e-3,
+              reward_scaling=1e-4)      # Stock_NeurIPS2018_SB3.py:251-272 (scalar costs)
+
+
+def cpu_baseline(close, tech, risk, budget_s=12.0):
+    """Time the oracle (oracle/stock_oracle.c, single thread) on a bounded sample of the same
+    workload: the first `Ec` envs of the batch, same panel, same action distribution."""
+    from oracle.stock import StockOracle
+    Ec, chunk = 256, 200
+    orc = StockOracle(close, tech, risk, n_envs=Ec, **ENV_KW)
+    orc.reset()
+    rng = np.random.default_rng(1234)
+    acts = rng.uniform(-1, 1, (8, Ec, close.shape[1])).astype(np.float32)
+    orc.vec_step(acts[0])               # warm
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        for j in range(chunk):
+            orc.vec_step(acts[j & 7])
+        steps += chunk
+        dt = time.perf_counter() - t0
+        if dt >= budget_s:
+            break
+    return dict(value=Ec * steps / dt, unit="env-steps/s", cores=1, kind="port",
+                sample=f"{Ec} envs x {steps} steps ({dt:.1f} s) of the same DOW30x8 workload, "
+                       "oracle/stock_oracle.c single thread, obs included "
+                       f"(host has {os.cpu_count()} cores)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3 * N_DAYS)
+    ap.add_argument("--warmup", type=int, default=N_DAYS)
+    ap.add_argument("--envs-per-gpu", type=int, default=E_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stats", action="store_true", help="disable on-device Sharpe stats")
+    ap.add_argument("--desync", action="store_true",
+                    help="per-env random start offsets (defeats panel-row broadcast)")
+    ap.add_argument("--action-pool", type=int, default=16)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from finrl_amd import StockPanel
+    from finrl_amd.vec_env import VecStockTradingEnv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local_rank)
+
+    E, N, K, T = args.envs_per_gpu, N_TICKERS, N_TECH, N_DAYS
+    close, tech, risk = synth_panel()
+    env = VecStockTradingEnv(StockPanel(close, tech, risk), E, device=dev,
+                             track_stats=not args.no_stats, auto_reset=True, **ENV_KW)
+    env.reset()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    pool = [torch.rand(E, N, generator=gen, device=dev) * 2 - 1 for _ in range(args.action_pool)]
+    if args.desync:     # walk every env to a random day by masked resets at random steps
+        offs = torch.randint(0, T - 1, (E,), generator=gen, device=dev)
+        env.state["day"].copy_(offs.to(torch.int32))
+        env.state["price_day"].copy_(offs.to(torch.int32))
+
+    gathered = torch.empty(world * E, dtype=torch.float32, device=dev) if world > 1 else None
+    step_in_ep = 0
+
+    def run(n):
+        nonlocal step_in_ep
+        for i in range(n):
+            env.step(pool[i % len(pool)])
+            step_in_ep += 1
+            if world > 1 and not args.desync and step_in_ep == T:
+                # episode end on every rank: gather per-env episode returns (RCCL, 256 KB/rank)
+                dist.all_gather_into_tensor(gathered, env.episode_return())
+            if step_in_ep == T:
+                step_in_ep = 0
+
+    run(args.warmup)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    run(args.steps)
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        tt = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+
+    if rank == 0:
+        B = algorithmic_bytes(N, K)
+        per_launch_s = dev_ms * 1e-3 / args.steps        # HIP events on the launch stream
+        achieved = B * E / per_launch_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("envs_per_gpu") == E and tj.get("kernel") == "stock_step":
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "env-steps/sec at N parallel envs (DOW30, 8 indicators)",
+            "value": world * E * args.steps / wall,
+            "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{E} vectorized StockTradingEnv per GPU, DOW30 x 8 "
+                                   f"indicators, T={T}, random actions"
+                                   + (", desynchronised start days" if args.desync else ""),
+                       "envs_per_gpu": E, "global_envs": world * E, "tickers": N,
+                       "indicators": K, "days": T, "track_stats": not args.no_stats,
+                       "parallelism": f"env-shard x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "stock_step_kernel", "bytes_per_env_step": B,
+                         "avg_launch_us": per_launch_s * 1e6},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(close, tech, risk)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
