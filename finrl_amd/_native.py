@@ -6,7 +6,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfinenv.so")
+# FINENV_LIB overrides the library path (diagnostic builds, e.g. libfinenv_diag.so)
+LIB_PATH = os.environ.get("FINENV_LIB") or os.path.join(_HERE, "lib", "libfinenv.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 FINENV_OK = 0
@@ -43,13 +44,14 @@ class StockPanelPtrs(C.Structure):
                 ("risk", C.c_void_p)]
 
 
-STOCK_STATE_FIELDS = ("cash", "holdings", "day", "price_day", "trades", "episode", "n_ret",
-                      "cost", "last_reward", "turbulence", "asset0", "prev_asset", "ret_mean",
-                      "ret_m2", "cash0", "shares0")
+# Field order of the two [field][E] state blocks (include/finenv.h enums)
+STOCK_F64_FIELDS = ("cash", "cost", "last_reward", "turbulence", "asset0", "prev_asset",
+                    "ret_mean", "ret_m2", "cash0")
+STOCK_I32_FIELDS = ("day", "price_day", "trades", "episode", "n_ret")
 
 
 class StockStatePtrs(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in STOCK_STATE_FIELDS]
+    _fields_ = [("f64", C.c_void_p), ("i32", C.c_void_p)]
 
 
 _lib = None
@@ -83,8 +85,14 @@ def lib():
     L.finenv_stock_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.finenv_stock_episode_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-    if L.finenv_abi_version() != 1:
-        raise NativeLibraryError("libfinenv.so ABI version mismatch; rebuild")
+    if L.finenv_abi_version() != 2:
+        raise NativeLibraryError("libfinenv.so ABI version mismatch; rebuild (make -C finrl_amd/csrc)")
+    L.finenv_struct_size.argtypes = [C.c_int]
+    for which, cls in enumerate((StockConfig, StockPanelPtrs, StockStatePtrs)):
+        if L.finenv_struct_size(which) != C.sizeof(cls):
+            raise NativeLibraryError(
+                f"ABI struct size mismatch for {cls.__name__}: python {C.sizeof(cls)} vs "
+                f"library {L.finenv_struct_size(which)}")
     _lib = L
     return L
 

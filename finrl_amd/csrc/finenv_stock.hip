@@ -24,9 +24,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
+#include <type_traits>
 
 #include "finenv.h"
 
@@ -58,7 +60,30 @@ struct Params {
     int32_t D;
     int32_t day0;
     uint32_t magicN;      // ceil(2^32 / N) for N >= 2 (exact f / N for f < 2^16)
+    int32_t diag;         // FINENV_DIAG builds only: phase-skip bitmask (timing experiments)
 };
+
+#ifdef FINENV_DIAG
+#define DIAG(bit) (p.diag & (bit))
+#else
+#define DIAG(bit) 0
+#endif
+
+// base (uniform, SGPR pair) + 32-bit per-lane BYTE offset: lets hipcc use the
+// `global_load/store v, v_off, s[base]` addressing form instead of keeping a 64-bit VGPR
+// address per array alive across the kernel.  Hosts validate that every offset fits 32 bits.
+template <typename T>
+__device__ __forceinline__ T *at(T *base, unsigned idx)
+{
+    return reinterpret_cast<T *>(
+        reinterpret_cast<char *>(const_cast<typename std::remove_const<T>::type *>(base)) +
+        (size_t)(idx * (unsigned)sizeof(T)));
+}
+// per-env state fields: [field][env] blocks (include/finenv.h)
+#define SF(fld) (*at(p.st.f64, (unsigned)(fld) * (unsigned)E + (unsigned)e))
+#define SI(fld) (*at(p.st.i32, (unsigned)(fld) * (unsigned)E + (unsigned)e))
+#define HOLD(i) SI(FINENV_STOCK_I32_FIELDS + (i))
+#define SH0(i) SI(FINENV_STOCK_I32_FIELDS + N + (i))
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -143,87 +168,197 @@ __device__ __forceinline__ double initial_asset(double cash0, const int (&h)[kNP
 // Stream observation rows for the envs selected by `lane_mask` (bit el = env e0+el).
 //   rows : per-wave LDS, rows[el*kRow + 0] = f32 cash, rows[el*kRow + 1 + i] = f32 holdings_i
 //   row_day (per lane el) = panel row whose prices/indicators go into that env's obs.
-// Chunk-outer / env-inner: one template register live, re-loaded only when the panel row
-// changes (never, in lock-step batches); every store instruction writes 256 contiguous B.
+// Chunk-outer / env-inner; every store instruction writes 256 contiguous bytes.
+// Fast path (all selected envs on the same panel row -- always, in lock-step batches): the
+// template chunk is loaded ONCE per chunk, so the env loop holds no load and its stores are
+// fire-and-forget (a load inside that loop makes hipcc wait vmcnt(0) per iteration, which
+// also drains every outstanding store: measured 45 us -> see DESIGN.md).
 __device__ __forceinline__ void write_obs_rows(float *__restrict__ dst,
                                                const float *__restrict__ tmpl, int D, int N,
                                                int e0, int nenv_w, int row_day,
                                                unsigned long long lane_mask,
-                                               const float *rows, int lane)
+                                               const float *rows, int lane, int k_lo = 0,
+                                               int k_hi = 1 << 30)
 {
-    const int nchunk = (D + kWave - 1) / kWave;
-    for (int k = 0; k < nchunk; ++k) {
+    if (lane_mask == 0ull) return;
+    const int nchunk = min(k_hi, (D + kWave - 1) / kWave);
+    const int first = __builtin_ctzll(lane_mask);
+    const int rd0 = __builtin_amdgcn_readlane(row_day, first);
+    const bool mine = (lane_mask >> lane) & 1ull;
+    const bool uniform_row = __all(!mine || row_day == rd0);
+    const unsigned long long full_mask = (nenv_w >= 64) ? ~0ull : ((1ull << nenv_w) - 1ull);
+    const bool all_rows = lane_mask == full_mask;
+    float *const base = dst + (size_t)e0 * D;
+
+    for (int k = k_lo; k < nchunk; ++k) {
         const int col = k * kWave + lane;
         const bool in = col < D;
         const int hidx = col - 1 - N;
         const bool patch = in && (col == 0 || (hidx >= 0 && hidx < N));
         const int sel = (col == 0) ? 0 : (patch ? 1 + hidx : 0);
         const bool any_patch = __any(patch);
-        int prev_rd = -1;
-        float t = 0.0f;
-        float *out = dst + (size_t)e0 * D + col;
-        for (int el = 0; el < nenv_w; ++el, out += D) {
-            if (!((lane_mask >> el) & 1ull)) continue;
-            const int rd = __builtin_amdgcn_readlane(row_day, el);
-            if (rd != prev_rd) {
-                t = in ? tmpl[(size_t)rd * D + col] : 0.0f;
-                prev_rd = rd;
+        if (uniform_row) {
+            const float t = in ? *at(tmpl, (unsigned)(rd0 * D + col)) : 0.0f;
+            if (all_rows && !any_patch) {
+#pragma unroll 8
+                for (int el = 0; el < nenv_w; ++el)
+                    if (in) *at(base, (unsigned)(el * D + col)) = t;
+            } else if (all_rows) {
+#pragma unroll 8
+                for (int el = 0; el < nenv_w; ++el) {
+                    const float pv = rows[el * kRow + sel];
+                    if (in) *at(base, (unsigned)(el * D + col)) = patch ? pv : t;
+                }
+            } else {
+                for (int el = 0; el < nenv_w; ++el) {
+                    if (!((lane_mask >> el) & 1ull)) continue;
+                    const float pv = rows[el * kRow + sel];
+                    if (in) *at(base, (unsigned)(el * D + col)) = patch ? pv : t;
+                }
             }
-            float v = t;
-            if (any_patch) {
+        } else {
+            for (int el = 0; el < nenv_w; ++el) {
+                if (!((lane_mask >> el) & 1ull)) continue;
+                const int rd = __builtin_amdgcn_readlane(row_day, el);
+                const float t = in ? *at(tmpl, (unsigned)(rd * D + col)) : 0.0f;
                 const float pv = rows[el * kRow + sel];
-                v = patch ? pv : t;
+                if (in) *at(base, (unsigned)(el * D + col)) = patch ? pv : t;
             }
-            if (in) *out = v;
         }
     }
 }
 
 // -------------------------------------------------------------------------------------
 // step(): env_stocktrading.py:220-357 (+ DummyVecEnv auto-reset when p.auto_reset)
+//
+// One 128-thread block per 64 envs, two specialised waves (lane = env in both):
+//   wave 0 "trader"  : owns the env state; sort, sells, buys, assets, reward; writes the
+//                      observation chunk(s) that contain cash/holdings, and the state.
+//   wave 1 "streamer": stages the action tile and the current price row into LDS for the
+//                      trader, then streams the market-data part of the observation rows
+//                      (chunks that hold no per-env value: 237 of 301 columns at DOW30x8).
+// At 65,536 envs there is exactly one trader wave per SIMD on the chip, i.e. no
+// thread-level parallelism to hide its latency; the streamer wave shares the SIMD and keeps
+// HBM writing while the trader computes (measured: DESIGN.md "stock_step").
 // -------------------------------------------------------------------------------------
+constexpr int kStepThreads = 2 * kWave;
+// Tuning switches (see tools/sweep_stock.py --variants; defaults = measured best)
+#ifndef FINENV_NREG_PIN
+#define FINENV_NREG_PIN 0         // next-row price loads: 0 hoistable, 1 after sells, 2 after buys
+#endif
+constexpr int kR1 = kWave * kRow;                 // dwords: act tile / holdings / obs rows
+constexpr int kR2 = kNPad * kWave * 2;            // dwords: f64 prices [ticker][lane]
+
 template <bool TURB, bool STATS>
-__global__ void __launch_bounds__(kWave *kWavesPerBlock)
+__global__ void __launch_bounds__(kStepThreads, 2)
 stock_step_kernel(const Params p)
 {
-    __shared__ float lds_all[kWavesPerBlock * kLdsPerWave];
+    __shared__ __attribute__((aligned(16))) float lds_all[kR1 + kR2];
     const int lane = threadIdx.x & (kWave - 1);
-    const int wib = threadIdx.x >> 6;
-    float *lds = lds_all + wib * kLdsPerWave;
-    int *ldsh = reinterpret_cast<int *>(lds);            // [ticker][lane] view
+    const int role = threadIdx.x >> 6;                    // 0 trader, 1 streamer
+    float *lds = lds_all;
+    int *ldsh = reinterpret_cast<int *>(lds_all);         // [ticker][lane] view of R1
+    double *ldsp = reinterpret_cast<double *>(lds_all + kR1);   // [ticker][lane] f64 prices
 
     const int E = p.cfg.n_envs, N = p.cfg.n_tickers, D = p.D, T = p.cfg.n_days;
-    const int e0 = (blockIdx.x * kWavesPerBlock + wib) * kWave;
-    if (e0 >= E) return;                                  // wave-uniform
+    const int e0 = blockIdx.x * kWave;
+    if (e0 >= E) return;                                  // block-uniform
     const int nenv_w = min(kWave, E - e0);
     const bool valid = lane < nenv_w;
     const int e = valid ? e0 + lane : e0;                 // clamped: tail lanes shadow env e0
 
-    // ---- A. action tile [nenv_w][N] f32: coalesced read, transpose through LDS ----------
-    {
-        const float *__restrict__ src = p.actions + (size_t)e0 * N;
-        const int total = nenv_w * N;
-        for (int f = lane; f < total; f += kWave) {
-            const int el = (N == 1) ? f : (int)__umulhi((unsigned)f, p.magicN);
-            const int i = f - el * N;
-            lds[el * kRow + i] = src[f];
+    // ---- both roles: which panel rows this step touches (needs only day / price_day) -----
+    int day = SI(FINENV_SI_DAY);
+    int pd = SI(FINENV_SI_PRICE_DAY);
+    const bool term = day >= T - 1;                                           // :221
+    const bool do_reset = term && p.auto_reset != 0;
+    const int pd_cur = pd;                            // row held in the current observation
+    const int pd_next = term ? pd : day + 1;          // row after the step, before any reset
+    const int row_obs = do_reset ? (p.cfg.reset_quirk ? pd : 0) : pd_next;
+    const unsigned long long valid_mask = __ballot(valid);
+    const unsigned long long term_mask = __ballot(term && valid);
+    const int kpatch = (2 * N) / kWave + 1;           // chunks holding cash/holdings columns
+
+    // values the trader loads before the barrier (declared here: one barrier call site)
+    double cash = 0.0, cost = 0.0, turb = 0.0, last_reward = 0.0;
+    double st_prev = 0.0, st_mean = 0.0, st_m2 = 0.0;
+    int trades = 0, st_n = 0;
+    int hreg[kNPad];
+
+    if (role == 1) {
+        // ---- streamer, part 1: stage current price row and the action tile in LDS ---------
+        double pv[kNPad];
+#pragma unroll
+        for (int i = 0; i < kNPad; ++i)
+            pv[i] = *at(p.panel.close, (unsigned)(pd_cur * N + (i < N ? i : 0)));
+        if (!DIAG(8)) {
+            const float *__restrict__ src = p.actions + (size_t)e0 * N;   // 16-B aligned
+            const int total = nenv_w * N;
+            const int n4 = total >> 2;
+            float4 v[kNPad / 4];
+#pragma unroll
+            for (int it = 0; it < kNPad / 4; ++it) {                      // 8 loads in flight
+                const int j = it * kWave + lane;
+                v[it] = reinterpret_cast<const float4 *>(src)[j < n4 ? j : 0];
+            }
+#pragma unroll
+            for (int it = 0; it < kNPad / 4; ++it) {
+                const int j = it * kWave + lane;
+                if (j < n4) {
+                    const float c[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int f = 4 * j + u;
+                        const int el = (N == 1) ? f : (int)__umulhi((unsigned)f, p.magicN);
+                        lds[el * kRow + (f - el * N)] = c[u];
+                    }
+                }
+            }
+            for (int f = 4 * n4 + lane; f < total; f += kWave) {          // < 4 leftover floats
+                const int el = (N == 1) ? f : (int)__umulhi((unsigned)f, p.magicN);
+                lds[el * kRow + (f - el * N)] = src[f];
+            }
         }
+#pragma unroll
+        for (int i = 0; i < kNPad; ++i) ldsp[i * kWave + lane] = pv[i];
+    } else {
+        // ---- trader, part 1: every global load it will ever need, issued up front ----------
+        cash = SF(FINENV_SF_CASH);
+        cost = SF(FINENV_SF_COST);
+        trades = SI(FINENV_SI_TRADES);
+        last_reward = SF(FINENV_SF_LAST_REWARD);
+        if (TURB) turb = SF(FINENV_SF_TURBULENCE);
+        if (STATS) {
+            st_prev = SF(FINENV_SF_PREV_ASSET);
+            st_n = SI(FINENV_SI_N_RET);
+            st_mean = SF(FINENV_SF_RET_MEAN);
+            st_m2 = SF(FINENV_SF_RET_M2);
+        }
+#pragma unroll
+        for (int i = 0; i < kNPad; ++i) hreg[i] = HOLD(i < N ? i : 0);
+    }
+    __syncthreads();
+
+    if (role == 1) {
+        // ---- streamer, part 2: market-data chunks of the observation rows -------------------
+        if (!DIAG(1)) {
+            if (term_mask != 0ull && p.term_obs != nullptr)
+                write_obs_rows(p.term_obs, p.panel.obs_tmpl, D, N, e0, nenv_w, pd_cur,
+                               term_mask, lds, lane, kpatch);
+            write_obs_rows(p.obs, p.panel.obs_tmpl, D, N, e0, nenv_w, row_obs, valid_mask, lds,
+                           lane, kpatch);
+        }
+        return;
     }
 
-    // ---- B. per-env scalars ---------------------------------------------------------------
-    int day = p.st.day[e];
-    int pd = p.st.price_day[e];
-    double cash = p.st.cash[e];
-    double cost = p.st.cost[e];
-    int trades = p.st.trades[e];
-    double turb = 0.0;
-    if (TURB) turb = p.st.turbulence[e];
-    const bool term = day >= T - 1;                                           // :221
+    // =========================== trader wave only below ===================================
     const bool turbulent = TURB && (turb >= p.cfg.turbulence_threshold);      // :308-310
     const int hmax = p.cfg.hmax;
     const float hmaxf = (float)hmax;
+    const uint32_t untr = *at(p.panel.untradable, (unsigned)pd_cur);
+    double risk_next = 0.0;
+    if (TURB) risk_next = *at(p.panel.risk, (unsigned)pd_next);
 
-    wave_sync();
     int keys[kNPad];
 #pragma unroll
     for (int i = 0; i < kNPad; ++i) {
@@ -236,67 +371,74 @@ stock_step_kernel(const Params p)
     }
     wave_sync();
 
-    // ---- C. holdings -> LDS [ticker][lane]; begin_total_asset (:311-314) ------------------
-    const double *__restrict__ prow = p.panel.close + (size_t)pd * N;
+    // ---- holdings -> LDS [ticker][lane]; begin_total_asset (:311-314) -----------------------
     double s = 0.0;
-    {
-        const int *__restrict__ hp = p.st.holdings + e;
-#pragma unroll 6
-        for (int i = 0; i < N; ++i) {
-            const int h = hp[(size_t)i * E];
-            ldsh[i * kWave + lane] = h;
-            s = s + prow[i] * (double)h;
-        }
+#pragma unroll
+    for (int i = 0; i < kNPad; ++i) {
+        const double t = s + ldsp[i * kWave + lane] * (double)hreg[i];
+        s = (i < N) ? t : s;
+        ldsh[i * kWave + lane] = hreg[i];          // slots >= N hold a harmless copy of slot 0
     }
     const double begin = cash + s;
-    const uint32_t untr = p.panel.untradable[pd];
 
-    // ---- D. canonical order ---------------------------------------------------------------
-    sort32(keys);
+    // ---- canonical order ----------------------------------------------------------------------
+    if (!DIAG(4)) sort32(keys);
 
     const double c_s = p.cfg.sell_cost_pct, c_b = p.cfg.buy_cost_pct;
     const double one_m_cs = 1 - c_s, one_p_cb = 1 + c_b;
 
-    // ---- E. sells: most negative first (:318, :321-324, _sell_stock :102-169) -------------
+    // ---- sells: most negative first (:317-324, _sell_stock :102-169) ---------------------------
+    // A ticker is sold OR bought at most once per step, so its holdings are read once and
+    // written once (no read-after-write through LDS).  Sells do not depend on cash
+    // (q = min(|a|, h)): each group of 8 ranks is resolved in parallel (LDS gathers, share
+    // counts, holdings updates), then its amounts are added to cash / cost serially in rank
+    // order -- the only part the reference's semantics force to be sequential.
+    int n_sold = 0;
 #pragma unroll
-    for (int r = 0; r < kNPad; ++r) {
-        const int key = keys[r];
-        const bool act = key < 0;
-        if (!__any(act)) break;
-        const int idx = key & (kNPad - 1);
-        const int a = key >> 5;
-        const int li = act ? idx : 0;
-        const double pr = prow[li];
-        const int h = ldsh[li * kWave + lane];
-        bool ok;
-        int q;
-        if (turbulent) {                                  // :139-163 (flag ignored)
-            ok = act && pr > 0.0 && h > 0;
-            q = h;
-        } else {                                          // :105-133
-            ok = act && !((untr >> idx) & 1u) && h > 0;
-            q = min(-a, h);
+    for (int g = 0; g < kNPad; g += 8) {
+        if (!__any(keys[g] < 0) || DIAG(2)) break;        // sorted: no sells beyond this rank
+        double amt[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int key = keys[g + u];
+            const int idx = key & (kNPad - 1);
+            const int a = key >> 5;
+            const int addr = idx * kWave + lane;
+            const int h = ldsh[addr];
+            const double pp = ldsp[addr];
+            // turbulent: sell everything, tradable flag ignored (:139-163); else :105-133
+            const bool ok = key < 0 && h > 0 &&
+                            (turbulent ? (pp > 0.0) : !((untr >> idx) & 1u));
+            const int q = ok ? (turbulent ? h : min(-a, h)) : 0;
+            if (ok) ldsh[addr] = h - q;                                       // :123
+            n_sold += ok ? 1 : 0;                                             // :129
+            amt[u] = pp * (double)q;
         }
-        if (ok) {
-            const double amt = pr * (double)q;
-            cash += amt * one_m_cs;
-            cost += amt * c_s;
-            trades += 1;
-            ldsh[li * kWave + lane] = h - q;
+        // ranks that sold nothing add +0.0, which leaves the fp64 sums bit-identical
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            cash = cash + amt[u] * one_m_cs;                                  // :115-121
+            cost = cost + amt[u] * c_s;                                       // :124-128
         }
     }
+    trades += n_sold;
 
-    // ---- F. buys: largest first (:319, :328-330, _buy_stock :171-213) ---------------------
+    // ---- buys: largest first (:319, :328-330, _buy_stock :171-213) ---------------------------
+    // Serial through cash.  The price of the next rank is fetched from LDS one iteration ahead.
+    double p_nxt = ldsp[(keys[kNPad - 1] & (kNPad - 1)) * kWave + lane];
 #pragma unroll
     for (int r = kNPad - 1; r >= 0; --r) {
-        const int key = keys[r];
-        const bool act = key >= kNPad;                    // a >= 1
+        int key = keys[r];
+        double prr = p_nxt;
+        // Pin this rank's operands to this iteration: otherwise hipcc hoists the pure per-rank
+        // arithmetic of all 32 ranks above the early exits (+140 live VGPRs).
+        asm volatile("" : "+v"(key), "+v"(prr));
+        const bool act = key >= kNPad && !DIAG(2);        // a >= 1
         if (!__any(act)) break;
+        if (r > 0) p_nxt = ldsp[(keys[r - 1] & (kNPad - 1)) * kWave + lane];
         const int idx = key & (kNPad - 1);
         const int a = key >> 5;
-        const int li = act ? idx : 0;
-        const double pr = prow[li];
-        const double unit = pr * one_p_cb;                // :179
+        const double unit = prr * one_p_cb;               // :179
         const bool ok = act && !turbulent && !((untr >> idx) & 1u) && unit > 0.0;
         // cash >= a*unit exactly  <=>  cash // unit >= a  (then min(avail, a) == a, :184)
         const bool full = fma(-(double)a, unit, cash) >= 0.0;
@@ -305,62 +447,70 @@ stock_step_kernel(const Params p)
             const double avail = floordiv_exact(cash, unit);                  // :178-180
             qd = full ? qd : avail;
         }
-        if (ok) {
-            const double amt = pr * qd;
-            cash -= amt * one_p_cb;                                           // :185-190
-            cost += amt * c_b;                                                // :194-196
-            trades += 1;                                                      // :197
-            ldsh[li * kWave + lane] += (int)qd;                               // :192
-        }
+        const double amt = prr * qd;
+        const double cash1 = cash - amt * one_p_cb;                           // :185-190
+        const double cost1 = cost + amt * c_b;                                // :194-196
+        cash = ok ? cash1 : cash;
+        cost = ok ? cost1 : cost;
+        trades += ok ? 1 : 0;                                                 // :197
+        if (ok) __hip_atomic_fetch_add(&ldsh[idx * kWave + lane], (int)qd, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WAVEFRONT);          // :192 (ds_add)
     }
 
-    // ---- G. day += 1, new row, end_total_asset, reward (:335-352) --------------------------
-    double last_reward = p.st.last_reward[e];
+    // ---- day += 1, new row, end_total_asset, reward (:335-352) --------------------------------
     if (!term) {
         day += 1;
         pd = day;
-        if (TURB) turb = p.panel.risk[day];
+        if (TURB) turb = risk_next;
     }
-    const double *__restrict__ nrow = p.panel.close + (size_t)pd * N;
+    double nreg[kNPad];
+#if FINENV_NREG_PIN != 1
+    {
+        const int pin = (FINENV_NREG_PIN == 2 && cash != cash) ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < kNPad; ++i)
+            nreg[i] = *at(p.panel.close, (unsigned)(pd_next * N + (i < N ? i : 0) + pin));
+    }
+#endif
     int hf[kNPad];
+#pragma unroll
+    for (int i = 0; i < kNPad; ++i) {
+        const int h = ldsh[i * kWave + lane];
+        hf[i] = (i < N) ? h : 0;
+    }
     s = 0.0;
 #pragma unroll
     for (int i = 0; i < kNPad; ++i) {
-        const int ii = i < N ? i : 0;
-        const int h = ldsh[ii * kWave + lane];
-        hf[i] = (i < N) ? h : 0;
-        const double t = s + nrow[ii] * (double)h;
+        const double t = s + nreg[i] * (double)hf[i];
         s = (i < N) ? t : s;
     }
     const double end = cash + s;
     if (!term) last_reward = (end - begin) * p.cfg.reward_scaling;
     if (valid) {
-        p.reward[e] = (float)last_reward;
-        p.done[e] = term ? 1 : 0;
+        *at(p.reward, (unsigned)e) = (float)last_reward;
+        *at(p.done, (unsigned)e) = term ? 1 : 0;
     }
     if (STATS && !term) {                    // running pct_change mean / M2, :243-251
-        const double prev = p.st.prev_asset[e];
-        const int n = p.st.n_ret[e] + 1;
-        double mean = p.st.ret_mean[e], m2 = p.st.ret_m2[e];
-        const double ret = end / prev - 1.0;
-        const double d1 = ret - mean;
-        mean += d1 / (double)n;
-        m2 += d1 * (ret - mean);
+        const int n = st_n + 1;
+        const double ret = end / st_prev - 1.0;
+        const double d1 = ret - st_mean;
+        st_mean += d1 / (double)n;
+        st_m2 += d1 * (ret - st_mean);
         if (valid) {
-            p.st.prev_asset[e] = end;
-            p.st.n_ret[e] = n;
-            p.st.ret_mean[e] = mean;
-            p.st.ret_m2[e] = m2;
+            SF(FINENV_SF_PREV_ASSET) = end;
+            SI(FINENV_SI_N_RET) = n;
+            SF(FINENV_SF_RET_MEAN) = st_mean;
+            SF(FINENV_SF_RET_M2) = st_m2;
         }
     }
     if (p.realised != nullptr) {             // traded shares == holdings delta (:324, :330)
 #pragma unroll
         for (int i = 0; i < kNPad; ++i)
             if (i < N && valid)
-                p.realised[(size_t)e * N + i] = hf[i] - p.st.holdings[(size_t)i * E + e];
+                *at(p.realised, (unsigned)(e * N + i)) = hf[i] - HOLD(i);
     }
 
-    // ---- H. observation rows in LDS; terminal obs; auto-reset -------------------------------
+    // ---- observation rows in LDS; terminal obs; auto-reset -------------------------------------
     wave_sync();
     lds[lane * kRow] = (float)cash;
 #pragma unroll
@@ -368,31 +518,29 @@ stock_step_kernel(const Params p)
         if (i < N) lds[lane * kRow + 1 + i] = (float)hf[i];
     wave_sync();
 
-    const unsigned long long valid_mask = __ballot(valid);
-    const unsigned long long term_mask = __ballot(term && valid);
     int episode_inc = 0;
     if (term_mask != 0ull) {                 // wave-uniform, once per episode
         if (p.term_obs != nullptr)
-            write_obs_rows(p.term_obs, p.panel.obs_tmpl, D, N, e0, nenv_w, pd, term_mask, lds,
-                           lane);
+            write_obs_rows(p.term_obs, p.panel.obs_tmpl, D, N, e0, nenv_w, pd_cur, term_mask,
+                           lds, lane, 0, kpatch);
         if (p.auto_reset) {                  // reset(), :359-393
             wave_sync();
             if (term) {
-                if (!p.cfg.reset_quirk) pd = 0;
-                cash = p.st.cash0[e];
+                pd = row_obs;
+                cash = SF(FINENV_SF_CASH0);
 #pragma unroll
                 for (int i = 0; i < kNPad; ++i) {
-                    const int v = p.st.shares0[(size_t)(i < N ? i : 0) * E + e];
+                    const int v = SH0(i < N ? i : 0);
                     hf[i] = (i < N) ? v : 0;
                 }
                 const double a0 = initial_asset(cash, hf, p.panel.close + (size_t)pd * N, N,
                                                 p.cfg.initial != 0);
                 if (valid) {
-                    p.st.asset0[e] = a0;
-                    p.st.prev_asset[e] = a0;
-                    p.st.ret_mean[e] = 0.0;
-                    p.st.ret_m2[e] = 0.0;
-                    p.st.n_ret[e] = 0;
+                    SF(FINENV_SF_ASSET0) = a0;
+                    SF(FINENV_SF_PREV_ASSET) = a0;
+                    SF(FINENV_SF_RET_MEAN) = 0.0;
+                    SF(FINENV_SF_RET_M2) = 0.0;
+                    SI(FINENV_SI_N_RET) = 0;
                 }
                 day = 0;
                 turb = 0.0;
@@ -408,22 +556,24 @@ stock_step_kernel(const Params p)
         }
     }
 
-    // ---- I. next observation [64][D] f32 (:342 / :453-478) ----------------------------------
-    write_obs_rows(p.obs, p.panel.obs_tmpl, D, N, e0, nenv_w, pd, valid_mask, lds, lane);
+    // ---- the observation chunk(s) holding cash / holdings (:342 / :453-478) ---------------------
+    if (!DIAG(1))
+        write_obs_rows(p.obs, p.panel.obs_tmpl, D, N, e0, nenv_w, row_obs, valid_mask, lds, lane,
+                       0, kpatch);
 
-    // ---- J. state write-back ------------------------------------------------------------------
+    // ---- state write-back --------------------------------------------------------------------------
     if (valid) {
-        p.st.cash[e] = cash;
-        p.st.cost[e] = cost;
-        p.st.trades[e] = trades;
-        p.st.day[e] = day;
-        p.st.price_day[e] = pd;
-        p.st.last_reward[e] = last_reward;
-        if (TURB) p.st.turbulence[e] = turb;
-        if (episode_inc) p.st.episode[e] += 1;
+        SF(FINENV_SF_CASH) = cash;
+        SF(FINENV_SF_COST) = cost;
+        SI(FINENV_SI_TRADES) = trades;
+        SI(FINENV_SI_DAY) = day;
+        SI(FINENV_SI_PRICE_DAY) = pd;
+        SF(FINENV_SF_LAST_REWARD) = last_reward;
+        if (TURB) SF(FINENV_SF_TURBULENCE) = turb;
+        if (episode_inc) SI(FINENV_SI_EPISODE) += 1;
 #pragma unroll
         for (int i = 0; i < kNPad; ++i)
-            if (i < N) p.st.holdings[(size_t)i * E + e] = hf[i];
+            if (i < N) HOLD(i) = hf[i];
     }
 }
 
@@ -449,45 +599,45 @@ __global__ void __launch_bounds__(kWave *kWavesPerBlock) stock_aux_kernel(const 
     int pd;
     bool sel = valid;
     if (mode == 2) {
-        cash = p.st.cash[e];
-        pd = p.st.price_day[e];
+        cash = SF(FINENV_SF_CASH);
+        pd = SI(FINENV_SI_PRICE_DAY);
 #pragma unroll
         for (int i = 0; i < kNPad; ++i) {
-            const int v = p.st.holdings[(size_t)(i < N ? i : 0) * E + e];
+            const int v = HOLD(i < N ? i : 0);
             hf[i] = (i < N) ? v : 0;
         }
     } else {
         if (mode == 1 && p.mask != nullptr) sel = valid && p.mask[e] != 0;
         if (mode == 0) pd = p.day0;
-        else pd = p.cfg.reset_quirk ? p.st.price_day[e] : 0;
-        cash = p.st.cash0[e];
+        else pd = p.cfg.reset_quirk ? SI(FINENV_SI_PRICE_DAY) : 0;
+        cash = SF(FINENV_SF_CASH0);
 #pragma unroll
         for (int i = 0; i < kNPad; ++i) {
-            const int v = p.st.shares0[(size_t)(i < N ? i : 0) * E + e];
+            const int v = SH0(i < N ? i : 0);
             hf[i] = (i < N) ? v : 0;
         }
         const double a0 =
             initial_asset(cash, hf, p.panel.close + (size_t)pd * N, N, p.cfg.initial != 0);
         if (sel) {
-            p.st.cash[e] = cash;
+            SF(FINENV_SF_CASH) = cash;
 #pragma unroll
             for (int i = 0; i < kNPad; ++i)
-                if (i < N) p.st.holdings[(size_t)i * E + e] = hf[i];
-            p.st.asset0[e] = a0;
-            p.st.prev_asset[e] = a0;
-            p.st.ret_mean[e] = 0.0;
-            p.st.ret_m2[e] = 0.0;
-            p.st.n_ret[e] = 0;
-            p.st.day[e] = (mode == 0) ? p.day0 : 0;
-            p.st.price_day[e] = pd;
-            p.st.turbulence[e] = 0.0;
-            p.st.cost[e] = 0.0;
-            p.st.trades[e] = 0;
+                if (i < N) HOLD(i) = hf[i];
+            SF(FINENV_SF_ASSET0) = a0;
+            SF(FINENV_SF_PREV_ASSET) = a0;
+            SF(FINENV_SF_RET_MEAN) = 0.0;
+            SF(FINENV_SF_RET_M2) = 0.0;
+            SI(FINENV_SI_N_RET) = 0;
+            SI(FINENV_SI_DAY) = (mode == 0) ? p.day0 : 0;
+            SI(FINENV_SI_PRICE_DAY) = pd;
+            SF(FINENV_SF_TURBULENCE) = 0.0;
+            SF(FINENV_SF_COST) = 0.0;
+            SI(FINENV_SI_TRADES) = 0;
             if (mode == 0) {
-                p.st.episode[e] = 0;
-                p.st.last_reward[e] = 0.0;
+                SI(FINENV_SI_EPISODE) = 0;
+                SF(FINENV_SF_LAST_REWARD) = 0.0;
             } else {
-                p.st.episode[e] += 1;
+                SI(FINENV_SI_EPISODE) += 1;
             }
         }
     }
@@ -506,22 +656,22 @@ __global__ void stock_stats_kernel(const Params p)
     const int E = p.cfg.n_envs, N = p.cfg.n_tickers;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
-    const double *prow = p.panel.close + (size_t)p.st.price_day[e] * N;
+    const double *prow = p.panel.close + (size_t)SI(FINENV_SI_PRICE_DAY) * N;
     double s = 0.0;
-    for (int i = 0; i < N; ++i) s = s + prow[i] * (double)p.st.holdings[(size_t)i * E + e];
-    const double end = p.st.cash[e] + s;
-    const double a0 = p.st.asset0[e];
+    for (int i = 0; i < N; ++i) s = s + prow[i] * (double)HOLD(i);
+    const double end = SF(FINENV_SF_CASH) + s;
+    const double a0 = SF(FINENV_SF_ASSET0);
     double *out = p.stats_out + (size_t)e * 6;
     out[0] = a0;
     out[1] = end;
     out[2] = end - a0;
-    out[3] = p.st.cost[e];
-    out[4] = (double)p.st.trades[e];
+    out[3] = SF(FINENV_SF_COST);
+    out[4] = (double)SI(FINENV_SI_TRADES);
     double sharpe = __builtin_nan("");
-    const int n = p.st.n_ret[e];
+    const int n = SI(FINENV_SI_N_RET);
     if (n >= 2) {
-        const double sd = sqrt(p.st.ret_m2[e] / (double)(n - 1));
-        if (sd != 0.0) sharpe = sqrt(252.0) * p.st.ret_mean[e] / sd;
+        const double sd = sqrt(SF(FINENV_SF_RET_M2) / (double)(n - 1));
+        if (sd != 0.0) sharpe = sqrt(252.0) * SF(FINENV_SF_RET_MEAN) / sd;
     }
     out[5] = sharpe;
 }
@@ -583,6 +733,16 @@ extern "C" {
 
 int finenv_abi_version(void) { return FINENV_ABI_VERSION; }
 
+int finenv_struct_size(int which)
+{
+    switch (which) {
+    case 0: return (int)sizeof(finenv_stock_config);
+    case 1: return (int)sizeof(finenv_stock_panel);
+    case 2: return (int)sizeof(finenv_stock_state);
+    default: return FINENV_ERR_INVALID;
+    }
+}
+
 const char *finenv_strerror(int code)
 {
     switch (code) {
@@ -615,6 +775,14 @@ int finenv_stock_create(const finenv_stock_config *cfg, finenv_stock **out)
     if ((long long)cfg->n_envs * (1 + 2 * cfg->n_tickers + cfg->n_tech * cfg->n_tickers) >
         (1ll << 40))
         return FINENV_ERR_INVALID;
+    {   // every device offset is a 32-bit byte offset from a uniform base (see at())
+        const long long E = cfg->n_envs, N = cfg->n_tickers, T = cfg->n_days;
+        const long long D = 1 + 2 * N + (long long)cfg->n_tech * N;
+        const long long lim = (1ll << 32) - 1;
+        if ((FINENV_STOCK_I32_FIELDS + 2 * N) * E * 4 > lim || FINENV_STOCK_F64_FIELDS * E * 8 > lim ||
+            T * D * 4 > lim || T * N * 8 > lim || E * N * 4 > lim)
+            return FINENV_ERR_INVALID;
+    }
     finenv_stock *h = new (std::nothrow) finenv_stock;
     if (!h) return FINENV_ERR_NOMEM;
     memset(h, 0, sizeof(*h));
@@ -640,10 +808,7 @@ int finenv_stock_bind(finenv_stock *h, const finenv_stock_panel *panel,
     if (!panel->close || !panel->obs_tmpl || !panel->untradable ||
         (h->cfg.use_turbulence && !panel->risk))
         return fail(h, FINENV_ERR_INVALID, "bind: null panel pointer%s");
-    if (!st->cash || !st->holdings || !st->day || !st->price_day || !st->trades ||
-        !st->episode || !st->n_ret || !st->cost || !st->last_reward || !st->turbulence ||
-        !st->asset0 || !st->prev_asset || !st->ret_mean || !st->ret_m2 || !st->cash0 ||
-        !st->shares0)
+    if (!st->f64 || !st->i32)
         return fail(h, FINENV_ERR_INVALID, "bind: null state pointer%s");
     h->panel = *panel;
     h->st = *st;
@@ -702,7 +867,13 @@ int finenv_stock_step(finenv_stock *h, const float *actions, float *obs, float *
     p.term_obs = term_obs;
     p.realised = realised;
     p.auto_reset = auto_reset;
-    const dim3 grid = grid_for(h->cfg.n_envs), block(kWave * kWavesPerBlock);
+#ifdef FINENV_DIAG
+    {
+        const char *d = getenv("FINENV_DIAG");
+        p.diag = d ? atoi(d) : 0;
+    }
+#endif
+    const dim3 grid((unsigned)((h->cfg.n_envs + kWave - 1) / kWave)), block(kStepThreads);
     const hipStream_t s = (hipStream_t)stream;
     const bool turb = h->cfg.use_turbulence != 0, stats = h->cfg.track_stats != 0;
     if (turb && stats) hipLaunchKernelGGL((stock_step_kernel<true, true>), grid, block, 0, s, p);

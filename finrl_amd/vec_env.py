@@ -81,21 +81,20 @@ class VecStockTradingEnv:
         if num_stock_shares is None:
             num_stock_shares = np.zeros(N, dtype=np.int64)
         sh0 = np.broadcast_to(np.asarray(num_stock_shares, dtype=np.int64), (E, N))
-        self.state = dict(
-            cash=torch.zeros(E, **f64), holdings=torch.zeros(N, E, **i32),
-            day=torch.zeros(E, **i32), price_day=torch.zeros(E, **i32),
-            trades=torch.zeros(E, **i32), episode=torch.zeros(E, **i32),
-            n_ret=torch.zeros(E, **i32), cost=torch.zeros(E, **f64),
-            last_reward=torch.zeros(E, **f64), turbulence=torch.zeros(E, **f64),
-            asset0=torch.zeros(E, **f64), prev_asset=torch.zeros(E, **f64),
-            ret_mean=torch.zeros(E, **f64), ret_m2=torch.zeros(E, **f64),
-            cash0=torch.from_numpy(np.ascontiguousarray(cash0)).to(dev),
-            shares0=torch.from_numpy(np.ascontiguousarray(sh0.T).astype(np.int32)).to(dev),
-        )
+        # two [field][E] blocks (include/finenv.h); self.state holds named views into them
+        nf, ni = len(nat.STOCK_F64_FIELDS), len(nat.STOCK_I32_FIELDS)
+        self._state_f64 = torch.zeros(nf, E, **f64)
+        self._state_i32 = torch.zeros(ni + 2 * N, E, **i32)
+        self.state = {k: self._state_f64[j] for j, k in enumerate(nat.STOCK_F64_FIELDS)}
+        self.state.update({k: self._state_i32[j] for j, k in enumerate(nat.STOCK_I32_FIELDS)})
+        self.state["holdings"] = self._state_i32[ni:ni + N]
+        self.state["shares0"] = self._state_i32[ni + N:ni + 2 * N]
+        self.state["cash0"].copy_(torch.from_numpy(np.array(cash0, dtype=np.float64)))
+        self.state["shares0"].copy_(torch.from_numpy(np.ascontiguousarray(sh0.T).astype(np.int32)))
         self._panel_t = panel.to_device(dev)
         pp = nat.StockPanelPtrs(*(self._panel_t[k].data_ptr()
                                   for k in ("close", "obs_tmpl", "untradable", "risk")))
-        sp = nat.StockStatePtrs(*(self.state[k].data_ptr() for k in nat.STOCK_STATE_FIELDS))
+        sp = nat.StockStatePtrs(self._state_f64.data_ptr(), self._state_i32.data_ptr())
         nat.check(L.finenv_stock_bind(self._h, C.byref(pp), C.byref(sp)), self._h, "bind")
 
         self.obs = torch.zeros(E, panel.D, dtype=torch.float32, device=dev)

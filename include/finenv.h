@@ -23,8 +23,9 @@
  *   actions  [E][N] f32 row-major  (what SB3 / ElegantRL hand over)
  *   obs      [E][D] f32 row-major  = [cash | close[N] | holdings[N] | tech[K][N]]
  *                                    (indicator-major, env_stocktrading.py:456-467)
- *   state    structure-of-arrays over envs; holdings is [N][E] (ticker-major) so that
- *            lane e of a wavefront reads holdings[i][e] coalesced.
+ *   state    structure-of-arrays over envs ([field][E] blocks); holdings is [N][E]
+ *            (ticker-major) so that lane e of a wavefront reads holdings[i][e] coalesced.
+ *   Limits   every device array must stay below 4 GiB (32-bit lane offsets).
  */
 #ifndef FINENV_H
 #define FINENV_H
@@ -35,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FINENV_ABI_VERSION 1
+#define FINENV_ABI_VERSION 2
 
 enum {
     FINENV_OK = 0,
@@ -85,31 +86,46 @@ typedef struct finenv_stock_panel {
                                      NULL when use_turbulence == 0)                      */
 } finenv_stock_panel;
 
-/* Mutable per-env state (device pointers, all caller-owned). */
+/* Mutable per-env state: two caller-owned device blocks of [field][env] arrays
+ * (structure-of-arrays; lane e of a wavefront touches element e of every field, so every
+ * access is coalesced, and two base pointers keep the kernels' scalar-register footprint
+ * small).  Field order: */
+enum {                            /* f64 block: double f64[FINENV_STOCK_F64_FIELDS][E]  */
+    FINENV_SF_CASH = 0,           /* state[0]                                            */
+    FINENV_SF_COST,               /* self.cost                                           */
+    FINENV_SF_LAST_REWARD,        /* self.reward (scaled; survives reset)                */
+    FINENV_SF_TURBULENCE,         /* self.turbulence                                     */
+    FINENV_SF_ASSET0,             /* asset_memory[0]                                     */
+    FINENV_SF_PREV_ASSET,         /* asset_memory[-1]                                    */
+    FINENV_SF_RET_MEAN,           /* Welford mean of pct_change(asset_memory)            */
+    FINENV_SF_RET_M2,             /* Welford M2                                          */
+    FINENV_SF_CASH0,              /* initial_amount / previous_state[0] (read-only)      */
+    FINENV_STOCK_F64_FIELDS
+};
+enum {                            /* i32 block: int32 i32[FINENV_STOCK_I32_FIELDS+2N][E] */
+    FINENV_SI_DAY = 0,            /* self.day                                            */
+    FINENV_SI_PRICE_DAY,          /* row whose prices/indicators sit in the current
+                                     observation (== day except right after a quirk
+                                     reset)                                              */
+    FINENV_SI_TRADES,             /* self.trades                                         */
+    FINENV_SI_EPISODE,            /* self.episode                                        */
+    FINENV_SI_N_RET,              /* number of daily returns accumulated                 */
+    FINENV_STOCK_I32_FIELDS       /* followed by holdings[N][E] = state[1+N .. 1+2N) and
+                                     shares0[N][E] = num_stock_shares / previous_state
+                                     shares (read-only)                                  */
+};
 typedef struct finenv_stock_state {
-    double  *cash;                /* [E]     state[0]                                    */
-    int32_t *holdings;            /* [N][E]  state[1+N .. 1+2N)                          */
-    int32_t *day;                 /* [E]     self.day                                    */
-    int32_t *price_day;           /* [E]     row whose prices/indicators sit in the
-                                             current observation (== day except right
-                                             after a quirk reset)                        */
-    int32_t *trades;              /* [E]     self.trades                                 */
-    int32_t *episode;             /* [E]     self.episode                                */
-    int32_t *n_ret;               /* [E]     number of daily returns accumulated         */
-    double  *cost;                /* [E]     self.cost                                   */
-    double  *last_reward;         /* [E]     self.reward (scaled; survives reset)        */
-    double  *turbulence;          /* [E]     self.turbulence                             */
-    double  *asset0;              /* [E]     asset_memory[0]                             */
-    double  *prev_asset;          /* [E]     asset_memory[-1]                            */
-    double  *ret_mean;            /* [E]     Welford mean of pct_change(asset_memory)    */
-    double  *ret_m2;              /* [E]     Welford M2                                  */
-    const double  *cash0;         /* [E]     initial_amount / previous_state[0]          */
-    const int32_t *shares0;       /* [N][E]  num_stock_shares / previous_state shares    */
+    double  *f64;                 /* [FINENV_STOCK_F64_FIELDS][E]                        */
+    int32_t *i32;                 /* [FINENV_STOCK_I32_FIELDS + 2N][E]                   */
 } finenv_stock_state;
 
 typedef struct finenv_stock finenv_stock;   /* opaque host-side handle */
 
 int         finenv_abi_version(void);
+/* sizeof() of the ABI structs as the library was compiled (0 = finenv_stock_config,
+ * 1 = finenv_stock_panel, 2 = finenv_stock_state): lets a foreign-language binding verify its
+ * struct declarations at load time instead of corrupting memory. */
+int         finenv_struct_size(int which);
 const char *finenv_strerror(int code);
 /* Number of HIP devices visible, or a negative FINENV_ERR_HIP. */
 int         finenv_device_count(void);

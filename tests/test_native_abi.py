@@ -1,0 +1,85 @@
+"""CPU-side checks of the C-ABI library: it loads (hipcc-built, no GPU needed), exports every
+symbol include/finenv.h declares, the ctypes struct layouts match the compiled ones, argument
+validation works, and launches fail loudly (never fall back) when no HIP device exists."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from finrl_amd import _native
+    _native.build()
+    return _native.lib()
+
+
+def test_exports_every_declared_symbol(L):
+    hdr = open(os.path.join(ROOT, "include", "finenv.h")).read()
+    names = sorted(set(re.findall(r"\b(finenv_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 13
+    for n in names:
+        assert hasattr(L, n), f"libfinenv.so does not export {n}"
+
+
+def test_struct_layouts_match(L):
+    from finrl_amd import _native as nat
+    assert L.finenv_abi_version() == 2
+    assert L.finenv_struct_size(0) == C.sizeof(nat.StockConfig)
+    assert L.finenv_struct_size(1) == C.sizeof(nat.StockPanelPtrs)
+    assert L.finenv_struct_size(2) == C.sizeof(nat.StockStatePtrs)
+    hdr = open(os.path.join(ROOT, "include", "finenv.h")).read()
+    f64 = re.findall(r"^\s+FINENV_SF_([A-Z0-9_]+)", hdr, flags=re.M)
+    i32 = re.findall(r"^\s+FINENV_SI_([A-Z0-9_]+)", hdr, flags=re.M)
+    assert tuple(x.lower() for x in f64) == nat.STOCK_F64_FIELDS
+    assert tuple(x.lower() for x in i32) == nat.STOCK_I32_FIELDS
+
+
+def test_create_validates_arguments(L):
+    from finrl_amd import _native as nat
+    h = C.c_void_p()
+    ok = nat.StockConfig(64, 30, 8, 100, 100, 0, 1, 1, 1, 0, 1e-3, 1e-3, 1e-4, 0.0)
+    assert L.finenv_stock_create(C.byref(ok), C.byref(h)) == 0
+    assert L.finenv_stock_obs_dim(h) == 301
+    # stepping before bind must fail with UNBOUND, not crash
+    assert L.finenv_stock_step(h, None, None, None, None, None, None, 1, None) == -2
+    assert b"bind" in L.finenv_stock_last_error(h)
+    L.finenv_stock_destroy(h)
+    for bad in (dict(n_tickers=33), dict(n_tickers=0), dict(n_envs=0), dict(n_days=0),
+                dict(hmax=-1), dict(n_envs=2**30)):
+        cfg = nat.StockConfig(64, 30, 8, 100, 100, 0, 1, 1, 1, 0, 1e-3, 1e-3, 1e-4, 0.0)
+        for k, v in bad.items():
+            setattr(cfg, k, v)
+        assert L.finenv_stock_create(C.byref(cfg), C.byref(h)) == -1, bad
+    assert L.finenv_strerror(-3) == b"HIP runtime error"
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device the product must refuse to run, not quietly compute on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from finrl_amd import StockPanel
+    from finrl_amd import _native as nat
+    from finrl_amd.vec_env import VecStockTradingEnv
+    panel = StockPanel(np.ones((4, 3)), np.zeros((4, 2, 3)), np.zeros(4))
+    with pytest.raises((nat.FinenvError, RuntimeError, AssertionError)):
+        VecStockTradingEnv(panel, 8, device="cpu")
+    with pytest.raises(Exception):
+        VecStockTradingEnv(panel, 8, device="cuda")
+    assert nat.lib().finenv_device_count() <= 0
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under finrl_amd/ may import or load it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "finrl_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("# oracle", "").lower() or \
+                    "import oracle" not in txt and "from oracle" not in txt and \
+                    "liboracle" not in txt, f
