@@ -46,7 +46,7 @@ class StockPanelPtrs(C.Structure):
 
 # Field order of the two [field][E] state blocks (include/finenv.h enums)
 STOCK_F64_FIELDS = ("cash", "cost", "last_reward", "turbulence", "asset0", "prev_asset",
-                    "ret_mean", "ret_m2", "cash0")
+                    "ret_sum", "ret_sumsq", "cash0")
 STOCK_I32_FIELDS = ("day", "price_day", "trades", "episode", "n_ret")
 
 

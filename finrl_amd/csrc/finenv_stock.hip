@@ -61,12 +61,23 @@ struct Params {
     int32_t day0;
     uint32_t magicN;      // ceil(2^32 / N) for N >= 2 (exact f / N for f < 2^16)
     int32_t diag;         // FINENV_DIAG builds only: phase-skip bitmask (timing experiments)
+    unsigned long long *dbg;   // FINENV_DIAG builds only: [block][role][16] s_memrealtime stamps
 };
 
 #ifdef FINENV_DIAG
 #define DIAG(bit) (p.diag & (bit))
+// phase stamps (100 MHz wall clock) for tools/phase_times.py; diagnostic build only
+#define STAMP(k)                                                                          \
+    do {                                                                                  \
+        if (p.dbg != nullptr && lane == 0) {                                              \
+            __builtin_amdgcn_sched_barrier(0);                                            \
+            p.dbg[((size_t)blockIdx.x * 2 + role) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+            __builtin_amdgcn_sched_barrier(0);                                            \
+        }                                                                                 \
+    } while (0)
 #else
 #define DIAG(bit) 0
+#define STAMP(k) do { } while (0)
 #endif
 
 // base (uniform, SGPR pair) + 32-bit per-lane BYTE offset: lets hipcc use the
@@ -165,6 +176,34 @@ __device__ __forceinline__ double initial_asset(double cash0, const int (&h)[kNP
     return cash0 + res;
 }
 
+// Same, with the starting shares in LDS (hcol[i * kWave] = shares of ticker i for this lane)
+// and rolled loops: the in-kernel auto-reset path runs once per episode and must not cost
+// registers or code size in the step kernel.
+__device__ __forceinline__ double initial_asset_lds(double cash0, const int *hcol,
+                                                    const double *__restrict__ close,
+                                                    unsigned row_base, int N, bool np_sum)
+{
+    auto prod = [&](int i) { return (double)hcol[i * kWave] * *at(close, row_base + (unsigned)i); };
+    double res = 0.0;
+    if (!np_sum) {
+        for (int i = 0; i < N; ++i) res = res + *at(close, row_base + (unsigned)i) * (double)hcol[i * kWave];
+    } else if (N < 8) {
+        for (int i = 0; i < N; ++i) res += prod(i);
+    } else {
+        double r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = prod(j);
+        const int full = N - (N & 7);
+        for (int i = 8; i < full; i += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] += prod(i + j);
+        }
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (int i = full; i < N; ++i) res += prod(i);
+    }
+    return cash0 + res;
+}
+
 // Stream observation rows for the envs selected by `lane_mask` (bit el = env e0+el).
 //   rows : per-wave LDS, rows[el*kRow + 0] = f32 cash, rows[el*kRow + 1 + i] = f32 holdings_i
 //   row_day (per lane el) = panel row whose prices/indicators go into that env's obs.
@@ -248,17 +287,20 @@ constexpr int kStepThreads = 2 * kWave;
 #endif
 constexpr int kR1 = kWave * kRow;                 // dwords: act tile / holdings / obs rows
 constexpr int kR2 = kNPad * kWave * 2;            // dwords: f64 prices [ticker][lane]
+constexpr int kR3 = kWave * kRow;                 // dwords: sorted keys [rank][lane] / obs rows
 
 template <bool TURB, bool STATS>
 __global__ void __launch_bounds__(kStepThreads, 2)
 stock_step_kernel(const Params p)
 {
-    __shared__ __attribute__((aligned(16))) float lds_all[kR1 + kR2];
+    __shared__ __attribute__((aligned(16))) float lds_all[kR1 + kR2 + kR3];
     const int lane = threadIdx.x & (kWave - 1);
     const int role = threadIdx.x >> 6;                    // 0 trader, 1 streamer
     float *lds = lds_all;
     int *ldsh = reinterpret_cast<int *>(lds_all);         // [ticker][lane] view of R1
     double *ldsp = reinterpret_cast<double *>(lds_all + kR1);   // [ticker][lane] f64 prices
+    int *ldsk = reinterpret_cast<int *>(lds_all + kR1 + kR2);   // [rank][lane] sorted keys
+    float *rows = lds_all + kR1 + kR2;                          // later: obs rows [env][kRow]
 
     const int E = p.cfg.n_envs, N = p.cfg.n_tickers, D = p.D, T = p.cfg.n_days;
     const int e0 = blockIdx.x * kWave;
@@ -267,6 +309,10 @@ stock_step_kernel(const Params p)
     const bool valid = lane < nenv_w;
     const int e = valid ? e0 + lane : e0;                 // clamped: tail lanes shadow env e0
 
+    STAMP(0);
+#ifdef FINENV_DIAG
+    if (p.dbg != nullptr && lane == 0) p.dbg[((size_t)blockIdx.x * 2 + role) * 16 + 14] = __builtin_amdgcn_s_memtime();
+#endif
     // ---- both roles: which panel rows this step touches (needs only day / price_day) -----
     int day = SI(FINENV_SI_DAY);
     int pd = SI(FINENV_SI_PRICE_DAY);
@@ -278,6 +324,7 @@ stock_step_kernel(const Params p)
     const unsigned long long valid_mask = __ballot(valid);
     const unsigned long long term_mask = __ballot(term && valid);
     const int kpatch = (2 * N) / kWave + 1;           // chunks holding cash/holdings columns
+    STAMP(1);
 
     // values the trader loads before the barrier (declared here: one barrier call site)
     double cash = 0.0, cost = 0.0, turb = 0.0, last_reward = 0.0;
@@ -331,13 +378,15 @@ stock_step_kernel(const Params p)
         if (STATS) {
             st_prev = SF(FINENV_SF_PREV_ASSET);
             st_n = SI(FINENV_SI_N_RET);
-            st_mean = SF(FINENV_SF_RET_MEAN);
-            st_m2 = SF(FINENV_SF_RET_M2);
+            st_mean = SF(FINENV_SF_RET_SUM);
+            st_m2 = SF(FINENV_SF_RET_SUMSQ);
         }
 #pragma unroll
         for (int i = 0; i < kNPad; ++i) hreg[i] = HOLD(i < N ? i : 0);
     }
+    STAMP(2);
     __syncthreads();
+    STAMP(3);
 
     if (role == 1) {
         // ---- streamer, part 2: market-data chunks of the observation rows -------------------
@@ -348,10 +397,15 @@ stock_step_kernel(const Params p)
             write_obs_rows(p.obs, p.panel.obs_tmpl, D, N, e0, nenv_w, row_obs, valid_mask, lds,
                            lane, kpatch);
         }
+        STAMP(4);
         return;
     }
 
     // =========================== trader wave only below ===================================
+    // Code-size note: only the key build, the begin-asset sum and the sorting network are
+    // unrolled (they need statically indexed VGPRs).  Everything after the sort is a rolled,
+    // software-pipelined loop over LDS-resident data: the fully unrolled form was ~55 KB of
+    // straight-line code per kernel, i.e. one pass through the whole instruction cache per wave.
     const bool turbulent = TURB && (turb >= p.cfg.turbulence_threshold);      // :308-310
     const int hmax = p.cfg.hmax;
     const float hmaxf = (float)hmax;
@@ -380,166 +434,161 @@ stock_step_kernel(const Params p)
         ldsh[i * kWave + lane] = hreg[i];          // slots >= N hold a harmless copy of slot 0
     }
     const double begin = cash + s;
+    STAMP(4);
 
-    // ---- canonical order ----------------------------------------------------------------------
+    // ---- canonical order, then park the sorted keys in LDS [rank][lane] ------------------------
     if (!DIAG(4)) sort32(keys);
+#pragma unroll
+    for (int r = 0; r < kNPad; ++r) ldsk[r * kWave + lane] = keys[r];
+    STAMP(5);
+
+    // next-row prices for end_total_asset: issued now (keys are parked, registers are free), so the
+    // loads fly during the trade loops instead of stalling the end of the step
+    double nreg[kNPad];
+#pragma unroll
+    for (int i = 0; i < kNPad; ++i)
+        nreg[i] = *at(p.panel.close, (unsigned)(pd_next * N + (i < N ? i : 0)));
 
     const double c_s = p.cfg.sell_cost_pct, c_b = p.cfg.buy_cost_pct;
     const double one_m_cs = 1 - c_s, one_p_cb = 1 + c_b;
+    const int *kcol = ldsk + lane;                 // this env's sorted keys, stride kWave
+    int *hcol = ldsh + lane;                       // this env's holdings by ticker, stride kWave
+    const double *pcol = ldsp + lane;              // this env's prices by ticker, stride kWave
 
     // ---- sells: most negative first (:317-324, _sell_stock :102-169) ---------------------------
     // A ticker is sold OR bought at most once per step, so its holdings are read once and
-    // written once (no read-after-write through LDS).  Sells do not depend on cash
-    // (q = min(|a|, h)): each group of 8 ranks is resolved in parallel (LDS gathers, share
-    // counts, holdings updates), then its amounts are added to cash / cost serially in rank
-    // order -- the only part the reference's semantics force to be sequential.
-    int n_sold = 0;
-#pragma unroll
-    for (int g = 0; g < kNPad; g += 8) {
-        if (!__any(keys[g] < 0) || DIAG(2)) break;        // sorted: no sells beyond this rank
-        double amt[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int key = keys[g + u];
-            const int idx = key & (kNPad - 1);
-            const int a = key >> 5;
-            const int addr = idx * kWave + lane;
-            const int h = ldsh[addr];
-            const double pp = ldsp[addr];
+    // written once (no read-after-write through LDS).  Two-deep software pipeline: the key of
+    // rank r+2 and the (holdings, price) of rank r+1 are in flight while rank r is applied.
+    // Ranks that sell nothing add +0.0 to cash / cost, which leaves the fp64 sums bit-identical
+    // to the reference skipping them.
+    if (!DIAG(2)) {
+        int key0 = kcol[0];
+        int key1 = kcol[1 * kWave];
+        int h0 = hcol[(key0 & (kNPad - 1)) * kWave];
+        double q0p = pcol[(key0 & (kNPad - 1)) * kWave];
+        int n_sold = 0;
+#pragma unroll 2
+        for (int r = 0; r < kNPad; ++r) {
+            if (!__any(key0 < 0)) break;               // sorted: no sells beyond this rank
+            const int key2 = kcol[min(r + 2, kNPad - 1) * kWave];
+            const int i1 = key1 & (kNPad - 1);
+            const int h1 = hcol[i1 * kWave];
+            const double p1 = pcol[i1 * kWave];
+
+            const int idx = key0 & (kNPad - 1);
+            const int a = key0 >> 5;
             // turbulent: sell everything, tradable flag ignored (:139-163); else :105-133
-            const bool ok = key < 0 && h > 0 &&
-                            (turbulent ? (pp > 0.0) : !((untr >> idx) & 1u));
-            const int q = ok ? (turbulent ? h : min(-a, h)) : 0;
-            if (ok) ldsh[addr] = h - q;                                       // :123
+            const bool ok = key0 < 0 && h0 > 0 &&
+                            (turbulent ? (q0p > 0.0) : !((untr >> idx) & 1u));
+            const int q = ok ? (turbulent ? h0 : min(-a, h0)) : 0;
+            hcol[idx * kWave] = h0 - q;                                       // :123
             n_sold += ok ? 1 : 0;                                             // :129
-            amt[u] = pp * (double)q;
+            const double amt = q0p * (double)q;
+            cash = cash + amt * one_m_cs;                                     // :115-121
+            cost = cost + amt * c_s;                                          // :124-128
+            key0 = key1; key1 = key2; h0 = h1; q0p = p1;
         }
-        // ranks that sold nothing add +0.0, which leaves the fp64 sums bit-identical
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            cash = cash + amt[u] * one_m_cs;                                  // :115-121
-            cost = cost + amt[u] * c_s;                                       // :124-128
-        }
+        trades += n_sold;
     }
-    trades += n_sold;
+    STAMP(6);
 
     // ---- buys: largest first (:319, :328-330, _buy_stock :171-213) ---------------------------
-    // Serial through cash.  The price of the next rank is fetched from LDS one iteration ahead.
-    double p_nxt = ldsp[(keys[kNPad - 1] & (kNPad - 1)) * kWave + lane];
-#pragma unroll
-    for (int r = kNPad - 1; r >= 0; --r) {
-        int key = keys[r];
-        double prr = p_nxt;
-        // Pin this rank's operands to this iteration: otherwise hipcc hoists the pure per-rank
-        // arithmetic of all 32 ranks above the early exits (+140 live VGPRs).
-        asm volatile("" : "+v"(key), "+v"(prr));
-        const bool act = key >= kNPad && !DIAG(2);        // a >= 1
-        if (!__any(act)) break;
-        if (r > 0) p_nxt = ldsp[(keys[r - 1] & (kNPad - 1)) * kWave + lane];
-        const int idx = key & (kNPad - 1);
-        const int a = key >> 5;
-        const double unit = prr * one_p_cb;               // :179
-        const bool ok = act && !turbulent && !((untr >> idx) & 1u) && unit > 0.0;
-        // cash >= a*unit exactly  <=>  cash // unit >= a  (then min(avail, a) == a, :184)
-        const bool full = fma(-(double)a, unit, cash) >= 0.0;
-        double qd = (double)a;
-        if (__any(ok && !full)) {
-            const double avail = floordiv_exact(cash, unit);                  // :178-180
-            qd = full ? qd : avail;
-        }
-        const double amt = prr * qd;
-        const double cash1 = cash - amt * one_p_cb;                           // :185-190
-        const double cost1 = cost + amt * c_b;                                // :194-196
-        cash = ok ? cash1 : cash;
-        cost = ok ? cost1 : cost;
-        trades += ok ? 1 : 0;                                                 // :197
-        if (ok) __hip_atomic_fetch_add(&ldsh[idx * kWave + lane], (int)qd, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WAVEFRONT);          // :192 (ds_add)
-    }
+    // Serial through cash: q = min(a, cash // unit), cash -= p*q*(1+c_b).  Everything that does
+    // not depend on cash is pipelined off the chain (key two ranks ahead, price + unit price +
+    // refined reciprocal one rank ahead).  On the chain, `cash // unit` is floor(cash*(1/unit))
+    // clamped to a, made exact by the sign of one FMA remainder (the estimate is within 1 of the
+    // true floor for |cash/unit| < 2^40; once it reaches a the test is the exact cash >= a*unit):
+    //   q0 = min(floor(cash*x), a);  rem = cash - q0*unit (exact sign)
+    //   rem < 0 -> q0-1;  rem >= unit and q0 < a -> q0+1;  else q0      == min(a, cash // unit)
+    if (!DIAG(2)) {
+        auto refined_rcp = [](double u) {
+            const double x = __builtin_amdgcn_rcp(u);
+            return fma(fma(-u, x, 1.0), x, x);
+        };
+        int key0 = kcol[(kNPad - 1) * kWave];
+        int key1 = kcol[(kNPad - 2) * kWave];
+        double p0 = pcol[(key0 & (kNPad - 1)) * kWave];
+        double u0 = p0 * one_p_cb;                                            // :179
+        double x0 = refined_rcp(u0);
+#pragma unroll 2
+        for (int r = kNPad - 1; r >= 0; --r) {
+            if (!__any(key0 >= kNPad)) break;          // sorted: no buys (a >= 1) below this rank
+            const int key2 = kcol[max(r - 2, 0) * kWave];
+            const double p1 = pcol[(key1 & (kNPad - 1)) * kWave];
+            const double u1 = p1 * one_p_cb;
+            const double x1 = refined_rcp(u1);
 
-    // ---- day += 1, new row, end_total_asset, reward (:335-352) --------------------------------
+            const int idx = key0 & (kNPad - 1);
+            const double ad = (double)(key0 >> 5);
+            const bool ok = key0 >= kNPad && !turbulent && !((untr >> idx) & 1u) && u0 > 0.0;
+            const double q0 = fmin(floor(cash * x0), ad);                     // :178-184
+            const double rem = fma(-q0, u0, cash);
+            const double adj = ((rem < 0.0) ? -1.0 : 0.0) + ((rem >= u0 && q0 < ad) ? 1.0 : 0.0);
+            const double qd = ok ? q0 + adj : 0.0;     // q = 0 leaves cash / cost bit-identical
+            const double amt = p0 * qd;
+            cash = cash - amt * one_p_cb;                                     // :185-190
+            cost = cost + amt * c_b;                                          // :194-196
+            trades += ok ? 1 : 0;                                             // :197
+            hcol[idx * kWave] += (int)qd;                                     // :192
+            key0 = key1; key1 = key2; p0 = p1; u0 = u1; x0 = x1;
+        }
+    }
+    STAMP(7);
+
+    // ---- day += 1, new row, end_total_asset (:335-347); obs rows -> LDS (keys are dead) -------
     if (!term) {
         day += 1;
         pd = day;
         if (TURB) turb = risk_next;
     }
-    double nreg[kNPad];
-#if FINENV_NREG_PIN != 1
-    {
-        const int pin = (FINENV_NREG_PIN == 2 && cash != cash) ? 1 : 0;
-#pragma unroll
-        for (int i = 0; i < kNPad; ++i)
-            nreg[i] = *at(p.panel.close, (unsigned)(pd_next * N + (i < N ? i : 0) + pin));
-    }
-#endif
-    int hf[kNPad];
-#pragma unroll
-    for (int i = 0; i < kNPad; ++i) {
-        const int h = ldsh[i * kWave + lane];
-        hf[i] = (i < N) ? h : 0;
-    }
+    wave_sync();
     s = 0.0;
 #pragma unroll
     for (int i = 0; i < kNPad; ++i) {
-        const double t = s + nreg[i] * (double)hf[i];
+        const int h = hcol[i * kWave];
+        const double t = s + nreg[i] * (double)h;
         s = (i < N) ? t : s;
+        if (i < N) rows[lane * kRow + 1 + i] = (float)h;
     }
+    rows[lane * kRow] = (float)cash;
     const double end = cash + s;
-    if (!term) last_reward = (end - begin) * p.cfg.reward_scaling;
+    STAMP(8);
+    if (!term) last_reward = (end - begin) * p.cfg.reward_scaling;            // :350-352
     if (valid) {
         *at(p.reward, (unsigned)e) = (float)last_reward;
         *at(p.done, (unsigned)e) = term ? 1 : 0;
     }
-    if (STATS && !term) {                    // running pct_change mean / M2, :243-251
-        const int n = st_n + 1;
-        const double ret = end / st_prev - 1.0;
-        const double d1 = ret - st_mean;
-        st_mean += d1 / (double)n;
-        st_m2 += d1 * (ret - st_mean);
-        if (valid) {
-            SF(FINENV_SF_PREV_ASSET) = end;
-            SI(FINENV_SI_N_RET) = n;
-            SF(FINENV_SF_RET_MEAN) = st_mean;
-            SF(FINENV_SF_RET_M2) = st_m2;
-        }
+    if (p.realised != nullptr && valid) {    // traded shares == holdings delta (:324, :330)
+        for (int i = 0; i < N; ++i)
+            *at(p.realised, (unsigned)(e * N + i)) = hcol[i * kWave] - HOLD(i);
     }
-    if (p.realised != nullptr) {             // traded shares == holdings delta (:324, :330)
-#pragma unroll
-        for (int i = 0; i < kNPad; ++i)
-            if (i < N && valid)
-                *at(p.realised, (unsigned)(e * N + i)) = hf[i] - HOLD(i);
-    }
-
-    // ---- observation rows in LDS; terminal obs; auto-reset -------------------------------------
-    wave_sync();
-    lds[lane * kRow] = (float)cash;
-#pragma unroll
-    for (int i = 0; i < kNPad; ++i)
-        if (i < N) lds[lane * kRow + 1 + i] = (float)hf[i];
+    STAMP(9);
     wave_sync();
 
+    // ---- terminal observation; auto-reset (once per episode, wave-uniform) ---------------------
     int episode_inc = 0;
-    if (term_mask != 0ull) {                 // wave-uniform, once per episode
+    if (term_mask != 0ull) {
         if (p.term_obs != nullptr)
             write_obs_rows(p.term_obs, p.panel.obs_tmpl, D, N, e0, nenv_w, pd_cur, term_mask,
-                           lds, lane, 0, kpatch);
+                           rows, lane, 0, kpatch);
         if (p.auto_reset) {                  // reset(), :359-393
             wave_sync();
             if (term) {
                 pd = row_obs;
                 cash = SF(FINENV_SF_CASH0);
-#pragma unroll
-                for (int i = 0; i < kNPad; ++i) {
-                    const int v = SH0(i < N ? i : 0);
-                    hf[i] = (i < N) ? v : 0;
+                for (int i = 0; i < N; ++i) {
+                    const int v = SH0(i);
+                    hcol[i * kWave] = v;
+                    rows[lane * kRow + 1 + i] = (float)v;
                 }
-                const double a0 = initial_asset(cash, hf, p.panel.close + (size_t)pd * N, N,
-                                                p.cfg.initial != 0);
+                rows[lane * kRow] = (float)cash;
+                const double a0 = initial_asset_lds(cash, hcol, p.panel.close, (unsigned)(pd * N),
+                                                    N, p.cfg.initial != 0);
                 if (valid) {
                     SF(FINENV_SF_ASSET0) = a0;
                     SF(FINENV_SF_PREV_ASSET) = a0;
-                    SF(FINENV_SF_RET_MEAN) = 0.0;
-                    SF(FINENV_SF_RET_M2) = 0.0;
+                    SF(FINENV_SF_RET_SUM) = 0.0;
+                    SF(FINENV_SF_RET_SUMSQ) = 0.0;
                     SI(FINENV_SI_N_RET) = 0;
                 }
                 day = 0;
@@ -547,10 +596,6 @@ stock_step_kernel(const Params p)
                 cost = 0.0;
                 trades = 0;
                 episode_inc = 1;
-                lds[lane * kRow] = (float)cash;
-#pragma unroll
-                for (int i = 0; i < kNPad; ++i)
-                    if (i < N) lds[lane * kRow + 1 + i] = (float)hf[i];
             }
             wave_sync();
         }
@@ -558,9 +603,21 @@ stock_step_kernel(const Params p)
 
     // ---- the observation chunk(s) holding cash / holdings (:342 / :453-478) ---------------------
     if (!DIAG(1))
-        write_obs_rows(p.obs, p.panel.obs_tmpl, D, N, e0, nenv_w, row_obs, valid_mask, lds, lane,
+        write_obs_rows(p.obs, p.panel.obs_tmpl, D, N, e0, nenv_w, row_obs, valid_mask, rows, lane,
                        0, kpatch);
+    STAMP(10);
 
+    // ---- running sums of pct_change(asset_memory) for the terminal Sharpe (:243-251) ------------
+    // Placed after the observation stores: nothing waits on it but its own write-back.
+    if (STATS && !term) {
+        const double ret = end / st_prev - 1.0;
+        if (valid) {
+            SF(FINENV_SF_PREV_ASSET) = end;
+            SI(FINENV_SI_N_RET) = st_n + 1;
+            SF(FINENV_SF_RET_SUM) = st_mean + ret;
+            SF(FINENV_SF_RET_SUMSQ) = st_m2 + ret * ret;
+        }
+    }
     // ---- state write-back --------------------------------------------------------------------------
     if (valid) {
         SF(FINENV_SF_CASH) = cash;
@@ -571,10 +628,13 @@ stock_step_kernel(const Params p)
         SF(FINENV_SF_LAST_REWARD) = last_reward;
         if (TURB) SF(FINENV_SF_TURBULENCE) = turb;
         if (episode_inc) SI(FINENV_SI_EPISODE) += 1;
-#pragma unroll
-        for (int i = 0; i < kNPad; ++i)
-            if (i < N) HOLD(i) = hf[i];
+#pragma unroll 6
+        for (int i = 0; i < N; ++i) HOLD(i) = hcol[i * kWave];
     }
+    STAMP(11);
+#ifdef FINENV_DIAG
+    if (p.dbg != nullptr && lane == 0) p.dbg[((size_t)blockIdx.x * 2 + role) * 16 + 15] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 // -------------------------------------------------------------------------------------
@@ -625,8 +685,8 @@ __global__ void __launch_bounds__(kWave *kWavesPerBlock) stock_aux_kernel(const 
                 if (i < N) HOLD(i) = hf[i];
             SF(FINENV_SF_ASSET0) = a0;
             SF(FINENV_SF_PREV_ASSET) = a0;
-            SF(FINENV_SF_RET_MEAN) = 0.0;
-            SF(FINENV_SF_RET_M2) = 0.0;
+            SF(FINENV_SF_RET_SUM) = 0.0;
+            SF(FINENV_SF_RET_SUMSQ) = 0.0;
             SI(FINENV_SI_N_RET) = 0;
             SI(FINENV_SI_DAY) = (mode == 0) ? p.day0 : 0;
             SI(FINENV_SI_PRICE_DAY) = pd;
@@ -669,9 +729,11 @@ __global__ void stock_stats_kernel(const Params p)
     out[4] = (double)SI(FINENV_SI_TRADES);
     double sharpe = __builtin_nan("");
     const int n = SI(FINENV_SI_N_RET);
-    if (n >= 2) {
-        const double sd = sqrt(SF(FINENV_SF_RET_M2) / (double)(n - 1));
-        if (sd != 0.0) sharpe = sqrt(252.0) * SF(FINENV_SF_RET_MEAN) / sd;
+    if (n >= 2) {        // sqrt(252) * mean / std(ddof=1) from the running sums
+        const double s1 = SF(FINENV_SF_RET_SUM), s2 = SF(FINENV_SF_RET_SUMSQ);
+        const double mean = s1 / (double)n;
+        const double var = (s2 - s1 * mean) / (double)(n - 1);
+        if (var > 0.0) sharpe = sqrt(252.0) * mean / sqrt(var);
     }
     out[5] = sharpe;
 }
@@ -728,6 +790,11 @@ dim3 grid_for(int E)
 }
 
 }  // namespace
+
+#ifdef FINENV_DIAG
+static unsigned long long *g_dbg = nullptr;
+extern "C" void finenv_diag_set_stamp_buffer(void *ptr) { g_dbg = (unsigned long long *)ptr; }
+#endif
 
 extern "C" {
 
@@ -871,6 +938,7 @@ int finenv_stock_step(finenv_stock *h, const float *actions, float *obs, float *
     {
         const char *d = getenv("FINENV_DIAG");
         p.diag = d ? atoi(d) : 0;
+        p.dbg = g_dbg;
     }
 #endif
     const dim3 grid((unsigned)((h->cfg.n_envs + kWave - 1) / kWave)), block(kStepThreads);

@@ -61,7 +61,7 @@ typedef struct finenv_stock_config {
                                      rewind (reference behaviour, :361 vs :380-381)      */
     int32_t initial;              /* `initial` flag, :70 -- selects the summation order
                                      of asset_memory[0] (:364-378)                       */
-    int32_t track_stats;          /* keep running mean/M2 of daily returns (Sharpe,
+    int32_t track_stats;          /* keep running sums of daily returns (Sharpe,
                                      :243-251) on device                                 */
     int32_t reserved0;
     double  buy_cost_pct;         /* scalar in this fork, :54                            */
@@ -97,8 +97,8 @@ enum {                            /* f64 block: double f64[FINENV_STOCK_F64_FIEL
     FINENV_SF_TURBULENCE,         /* self.turbulence                                     */
     FINENV_SF_ASSET0,             /* asset_memory[0]                                     */
     FINENV_SF_PREV_ASSET,         /* asset_memory[-1]                                    */
-    FINENV_SF_RET_MEAN,           /* Welford mean of pct_change(asset_memory)            */
-    FINENV_SF_RET_M2,             /* Welford M2                                          */
+    FINENV_SF_RET_SUM,            /* sum of pct_change(asset_memory) this episode        */
+    FINENV_SF_RET_SUMSQ,          /* sum of its squares (Sharpe at the terminal step)    */
     FINENV_SF_CASH0,              /* initial_amount / previous_state[0] (read-only)      */
     FINENV_STOCK_F64_FIELDS
 };

@@ -52,7 +52,7 @@ typedef struct {
     double  turbulence;         /* self.turbulence                                   */
     double  asset0;             /* asset_memory[0]                                   */
     double  prev_asset;         /* asset_memory[-1]                                  */
-    double  ret_mean, ret_m2;   /* Welford over pct_change(asset_memory)             */
+    double  ret_sum, ret_sumsq; /* running sums of pct_change(asset_memory)          */
     int32_t n_ret;
     int32_t day;                /* self.day                                          */
     int32_t price_day;          /* day whose row sits in self.state / self.data      */
@@ -206,7 +206,7 @@ void stock_oracle_reset_env(stock_oracle *o, int e, double *obs /* [D] or NULL *
     memcpy(o->shares + (size_t)e * N, o->shares0 + (size_t)e * N, N * sizeof(int64_t));
     s->asset0 = initial_asset(o, e, s->price_day);
     s->prev_asset = s->asset0;
-    s->ret_mean = 0.0; s->ret_m2 = 0.0; s->n_ret = 0;
+    s->ret_sum = 0.0; s->ret_sumsq = 0.0; s->n_ret = 0;
     if (obs) write_obs(o, e, s->price_day, obs);
     s->day = 0;
     s->turbulence = 0.0;
@@ -314,9 +314,8 @@ void stock_oracle_step_env(stock_oracle *o, int e, const float *act, double *obs
     {   /* running form of df_total_value.pct_change(1) mean/std, :243-251 */
         const double ret = end / s->prev_asset - 1.0;
         s->n_ret += 1;
-        const double d1 = ret - s->ret_mean;
-        s->ret_mean += d1 / (double)s->n_ret;
-        s->ret_m2 += d1 * (ret - s->ret_mean);
+        s->ret_sum = s->ret_sum + ret;
+        s->ret_sumsq = s->ret_sumsq + ret * ret;
         s->prev_asset = end;
     }
     *reward = s->last_reward;
@@ -390,9 +389,10 @@ void stock_oracle_episode_stats(const stock_oracle *o, double *out /* [E][6] */)
         r[3] = s->cost;
         r[4] = (double)s->trades;
         r[5] = NAN;
-        if (s->n_ret >= 2) {
-            const double sd = sqrt(s->ret_m2 / (double)(s->n_ret - 1));
-            if (sd != 0.0) r[5] = sqrt(252.0) * s->ret_mean / sd;
+        if (s->n_ret >= 2) {    /* sqrt(252) * mean / std(ddof=1) from the running sums */
+            const double mean = s->ret_sum / (double)s->n_ret;
+            const double var = (s->ret_sumsq - s->ret_sum * mean) / (double)(s->n_ret - 1);
+            if (var > 0.0) r[5] = sqrt(252.0) * mean / sqrt(var);
         }
     }
 }

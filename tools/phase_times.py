@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Per-phase timeline of the stock_step kernel from in-kernel s_memrealtime stamps
+(diagnostic library only: FINENV_LIB=finrl_amd/lib/libfinenv_diag.so).  Shares, not
+absolute run time: the stamped build is slower than the product build."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("FINENV_LIB", os.path.join(ROOT, "finrl_amd", "lib", "libfinenv_diag.so"))
+
+
+def main():
+    E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+    import torch
+    import bench
+    from finrl_amd import StockPanel, _native as nat
+    from finrl_amd.vec_env import VecStockTradingEnv
+    close, tech, risk = bench.synth_panel()
+    env = VecStockTradingEnv(StockPanel(close, tech, risk), E, **bench.ENV_KW)
+    env.reset()
+    nb = (E + 63) // 64
+    buf = torch.zeros(nb * 2 * 16, dtype=torch.int64, device="cuda")
+    pool = [torch.rand(E, 30, device="cuda") * 2 - 1 for _ in range(8)]
+    for i in range(200):
+        env.step(pool[i & 7])
+    L = nat.lib()
+    L.finenv_diag_set_stamp_buffer.argtypes = [C.c_void_p]
+    L.finenv_diag_set_stamp_buffer(C.c_void_p(buf.data_ptr()))
+    acc = []
+    for i in range(20):
+        buf.zero_()
+        env.step(pool[i & 7])
+        torch.cuda.synchronize()
+        acc.append(buf.cpu().numpy().reshape(nb, 2, 16).astype(np.float64) * 0.01)  # -> us
+    a = np.stack(acc)                                   # [rep, block, role, stamp]
+    t0 = a[:, :, :, 0].min(axis=(1, 2), keepdims=True)[..., None]
+    rel = a - t0
+    names_t = ["start", "day/pd loaded", "pre-barrier work done", "barrier passed",
+               "begin asset", "sorted", "sells done", "buys done", "end asset", "reward/stats",
+               "obs chunk0 written", "state written"]
+    names_s = ["start", "day/pd loaded", "tile+prices staged", "barrier passed", "streamed"]
+    print(f"E={E} blocks={nb}; times in us since the first wave of the launch started "
+          "(median over blocks and 20 launches; p95 in brackets)")
+    print("trader wave:")
+    for k, n in enumerate(names_t):
+        v = rel[:, :, 0, k].reshape(-1)
+        print(f"  {k:2d} {n:24s} {np.median(v):7.2f}  [{np.percentile(v, 95):7.2f}]")
+    print("streamer wave:")
+    for k, n in enumerate(names_s):
+        v = rel[:, :, 1, k].reshape(-1)
+        print(f"  {k:2d} {n:24s} {np.median(v):7.2f}  [{np.percentile(v, 95):7.2f}]")
+    cyc = (a[:, :, 0, 15] - a[:, :, 0, 14]) / 0.01          # raw shader-clock ticks
+    us = a[:, :, 0, 11] - a[:, :, 0, 0]
+    print(f"trader shader clock: {np.median(cyc / us) / 1e3:.2f} GHz (s_memtime ticks / s_memrealtime us)")
+    last = rel[:, :, 0, 11].max(axis=1)
+    print(f"last trader finishes at {np.median(last):.2f} us; last streamer at "
+          f"{np.median(rel[:, :, 1, 4].max(axis=1)):.2f} us")
+
+
+if __name__ == "__main__":
+    main()
