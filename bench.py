@@ -94,6 +94,7 @@ def main():
     import torch
     import torch.distributed as dist
     from finrl_amd import StockPanel
+    from finrl_amd.distributed import gather_episode_returns
     from finrl_amd.vec_env import VecStockTradingEnv
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,17 +120,17 @@ def main():
         env.state["day"].copy_(offs.to(torch.int32))
         env.state["price_day"].copy_(offs.to(torch.int32))
 
-    gathered = torch.empty(world * E, dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = None
     step_in_ep = 0
 
     def run(n):
-        nonlocal step_in_ep
+        nonlocal step_in_ep, gathered
         for i in range(n):
             env.step(pool[i % len(pool)])
             step_in_ep += 1
             if world > 1 and not args.desync and step_in_ep == T:
                 # episode end on every rank: gather per-env episode returns (RCCL, 256 KB/rank)
-                dist.all_gather_into_tensor(gathered, env.episode_return())
+                gathered = gather_episode_returns(env.episode_return(), world * E)
             if step_in_ep == T:
                 step_in_ep = 0
 

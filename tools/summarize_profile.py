@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 outputs of tools/profile_stock.sh into a small JSON + text summary
+(average kernel duration; FETCH_SIZE / WRITE_SIZE per launch with the gfx950 corrections of
+MI355X_MICROARCH.md section HBM)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def find(d, pat):
+    r = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    return r[0] if r else None
+
+
+def kernel_stats(d):
+    f = find(d, "*kernel_stats.csv")
+    out = {}
+    if f:
+        for row in csv.DictReader(open(f)):
+            if "stock_step_kernel" in row["Name"]:
+                out = dict(name=row["Name"], calls=int(row["Calls"]),
+                           avg_ns=float(row["AverageNs"]), min_ns=float(row["MinNs"]),
+                           max_ns=float(row["MaxNs"]), pct=float(row["Percentage"]))
+    return out
+
+
+def pmc(d, counter):
+    f = find(d, "*counter_collection.csv")
+    vals = []
+    if f:
+        for row in csv.DictReader(open(f)):
+            if "stock_step_kernel" in row.get("Kernel_Name", "") and \
+                    row.get("Counter_Name") == counter:
+                vals.append(float(row["Counter_Value"]))
+    return vals
+
+
+def main():
+    d = sys.argv[1]
+    ks = kernel_stats(os.path.join(d, "trace"))
+    fetch = pmc(os.path.join(d, "pmc_fetch"), "FETCH_SIZE")
+    write = pmc(os.path.join(d, "pmc_write"), "WRITE_SIZE")
+    med = lambda v: sorted(v)[len(v) // 2] if v else None
+    f_kb, w_kb = med(fetch), med(write)
+    res = dict(kernel=ks, fetch_size_kb_per_launch=f_kb, write_size_kb_per_launch=w_kb,
+               n_fetch_samples=len(fetch), n_write_samples=len(write))
+    if f_kb is not None and w_kb is not None:
+        # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  gfx950: FETCH_SIZE tallies 128-B
+        # requests at 64 B for wide coalesced reads -> the guide says double it; WRITE_SIZE is
+        # exact for streaming stores.  Both raw and corrected totals are kept.
+        res["hbm_bytes_per_launch_raw"] = (f_kb + w_kb) * 1024
+        res["hbm_bytes_per_launch"] = (2 * f_kb + w_kb) * 1024
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
