@@ -229,6 +229,28 @@ __device__ __forceinline__ void write_obs_rows(float *__restrict__ dst,
     const bool all_rows = lane_mask == full_mask;
     float *const base = dst + (size_t)e0 * D;
 
+    // Streamer fast path: row-major order (all chunks of a row back to back).  Rows are 1204 B,
+    // so a 256-B store chunk straddles 64-B memory segments; writing the neighbouring chunk of
+    // the same row immediately lets L2 merge the two halves before they leave for HBM
+    // (chunk-major order left them ~64 stores apart: WRITE_SIZE 1.19x the bytes stored).
+    if (uniform_row && all_rows && k_lo >= (2 * N) / kWave + 1 && nchunk - k_lo <= 8) {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int col = (k_lo + j) * kWave + lane;
+            t[j] = (col < D) ? *at(tmpl, (unsigned)(rd0 * D + col)) : 0.0f;
+        }
+#pragma unroll 2
+        for (int el = 0; el < nenv_w; ++el) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int col = (k_lo + j) * kWave + lane;
+                if (k_lo + j < nchunk && col < D) *at(base, (unsigned)(el * D + col)) = t[j];
+            }
+        }
+        return;
+    }
+
     for (int k = k_lo; k < nchunk; ++k) {
         const int col = k * kWave + lane;
         const bool in = col < D;
@@ -529,7 +551,10 @@ stock_step_kernel(const Params p)
             cash = cash - amt * one_p_cb;                                     // :185-190
             cost = cost + amt * c_b;                                          // :194-196
             trades += ok ? 1 : 0;                                             // :197
-            hcol[idx * kWave] += (int)qd;                                     // :192
+            // ds_add (no return): a plain `+=` is an LDS read-modify-write whose wait stalls
+            // every iteration of this serial loop for a full LDS round trip
+            __hip_atomic_fetch_add(&hcol[idx * kWave], (int)qd, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WAVEFRONT);              // :192
             key0 = key1; key1 = key2; p0 = p1; u0 = u1; x0 = x1;
         }
     }
