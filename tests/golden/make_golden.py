@@ -222,11 +222,94 @@ STOCK_SCENARIOS = {
 }
 
 
+# ----------------------------------------------------------------- portfolio env
+def run_portfolio(name, *, seed, T, N, K, S, initial_amount=1_000_000, lookback=8,
+                  act_scale=1.0):
+    """Unmodified reference StockPortfolioEnv (env_portfolio.py) on a synthetic frame with a
+    per-day covariance object column (`cov_list`), as the reference's tutorials build it."""
+    import pandas as pd
+    mod = rh.load_portfolio()
+    rng = np.random.default_rng(seed + 2000)
+    close, tech, _ = synth_panel(seed, T, N, K, fp32_prices=False)
+    rets = np.diff(np.log(close), axis=0, prepend=np.log(close[:1]))
+    cov = np.empty((T, N, N))
+    for t in range(T):
+        w = rets[max(0, t - lookback):t + 1]
+        cov[t] = np.cov(w.T) if len(w) > 1 else np.eye(N) * 1e-4
+        if N == 1:
+            cov[t] = np.atleast_2d(cov[t])
+    names = [f"ind{k}" for k in range(K)]
+    cols = {"date": np.repeat([f"d{t:04d}" for t in range(T)], N),
+            "tic": np.tile([f"TIC{i:03d}" for i in range(N)], T),
+            "close": close.reshape(-1)}
+    for k, nme in enumerate(names):
+        cols[nme] = tech[:, k, :].reshape(-1)
+    df = pd.DataFrame(cols)
+    df["cov_list"] = [cov[t] for t in range(T) for _ in range(N)]
+    df.index = np.repeat(np.arange(T), N)
+    act = (rng.uniform(0, 1, (S, N)) * act_scale).astype(np.float32)
+    rec = dict(obs=[], reward=[], done=[], value=[], day=[], weights=[], reset_step=[],
+               reset_obs=[])
+    printed = io.StringIO()
+    cwd = os.getcwd()
+    os.makedirs("/tmp/golden_work/results", exist_ok=True)
+    os.chdir("/tmp/golden_work")
+    try:
+        with contextlib.redirect_stdout(printed):
+            env = mod.StockPortfolioEnv(df=df, stock_dim=N, hmax=100,
+                                        initial_amount=initial_amount, transaction_cost_pct=0.001,
+                                        reward_scaling=1e-4, state_space=N, action_space=N,
+                                        tech_indicator_list=names)
+            rec["reset_step"].append(-1)
+            rec["reset_obs"].append(np.asarray(env.reset(), dtype=np.float64).reshape(-1))
+            for s in range(S):
+                n_w = len(env.actions_memory)
+                obs, rew, done, info = env.step(act[s].copy())
+                rec["obs"].append(np.asarray(obs, dtype=np.float64).reshape(-1))
+                rec["reward"].append(float(rew))
+                rec["done"].append(bool(done))
+                rec["value"].append(float(env.portfolio_value))
+                rec["day"].append(int(env.day))
+                rec["weights"].append(np.asarray(env.actions_memory[-1], dtype=np.float32)
+                                      if len(env.actions_memory) > n_w
+                                      else np.zeros(N, np.float32))
+                if done:
+                    rec["reset_step"].append(s)
+                    rec["reset_obs"].append(np.asarray(env.reset(), dtype=np.float64).reshape(-1))
+    finally:
+        os.chdir(cwd)
+    out = dict(close=close, cov=cov, tech=tech, actions=act,
+               cfg_int=np.array([T, N, K, S], dtype=np.int64),
+               cfg_float=np.array([initial_amount], dtype=np.float64),
+               obs=np.stack(rec["obs"]), reward=np.asarray(rec["reward"]),
+               done=np.asarray(rec["done"]), value=np.asarray(rec["value"]),
+               day=np.asarray(rec["day"], dtype=np.int64), weights=np.stack(rec["weights"]),
+               reset_step=np.asarray(rec["reset_step"], dtype=np.int64),
+               reset_obs=np.stack(rec["reset_obs"]),
+               meta=np.array(["variant=O-raw", f"seed={seed}", f"numpy={np.__version__}",
+                              "source=finrl/meta/env_portfolio_allocation/env_portfolio.py "
+                              "(unmodified)"]))
+    path = os.path.join(HERE, f"portfolio_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB) steps={S} "
+          f"dones={int(np.sum(rec['done']))} final_value={rec['value'][-1]:.2f}")
+    return out
+
+
+PORTFOLIO_SCENARIOS = {
+    "dow30": dict(seed=31, T=20, N=30, K=8, S=48),
+    "n5": dict(seed=32, T=16, N=5, K=2, S=40, initial_amount=50_000, act_scale=3.0),
+    "n2k1": dict(seed=33, T=12, N=2, K=1, S=30, initial_amount=1_000),
+}
+
+
 def main(argv):
-    names = argv or list(STOCK_SCENARIOS)
+    names = argv or (list(STOCK_SCENARIOS) + ["portfolio:" + k for k in PORTFOLIO_SCENARIOS])
     for n in names:
         if n in STOCK_SCENARIOS:
             run_stock(n, **STOCK_SCENARIOS[n])
+        elif n.startswith("portfolio:") and n[10:] in PORTFOLIO_SCENARIOS:
+            run_portfolio(n[10:], **PORTFOLIO_SCENARIOS[n[10:]])
         else:
             raise SystemExit(f"unknown scenario {n}")
 
