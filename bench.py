@@ -78,8 +78,49 @@ def cpu_baseline(close, tech, risk, budget_s=12.0):
                        f"(host has {os.cpu_count()} cores)")
 
 
+def bench_portfolio(args, torch, dev):
+    """BASELINE.json configs[2]: 65,536 vectorised StockPortfolioEnv, DOW30, K=8 (side metric;
+    the driver's default line is the stock env)."""
+    from finrl_amd.panel import PortfolioPanel
+    from finrl_amd.vec_portfolio import VecStockPortfolioEnv
+    E, N, K, T = args.envs_per_gpu, N_TICKERS, N_TECH, N_DAYS
+    close, tech, _ = synth_panel()
+    rets = np.diff(np.log(close), axis=0, prepend=np.log(close[:1]))
+    cov = np.einsum("ti,tj->tij", rets, rets).astype(np.float32).astype(np.float64)
+    env = VecStockPortfolioEnv(PortfolioPanel(close, cov, tech), E, device=dev)
+    env.reset()
+    pool = [torch.rand(E, N, device=dev) for _ in range(8)]
+    for i in range(args.warmup):
+        env.step(pool[i & 7])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()
+    for i in range(args.steps):
+        env.step(pool[i & 7])
+    e1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    B = 4 * N + 24 + 4 * N * (N + K) + 5           # SURVEY.md 8(d): 4709 B at N=30, K=8
+    per = e0.elapsed_time(e1) * 1e-3 / args.steps
+    ach = B * E / per / 1e9
+    print(json.dumps({
+        "metric": "env-steps/sec, vectorized StockPortfolioEnv (DOW30, 8 indicators)",
+        "value": E * args.steps / wall, "unit": "env-steps/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"{E} vectorized StockPortfolioEnv, DOW30 x 8, T={T}",
+                   "envs_per_gpu": E},
+        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "portfolio_step_kernel", "bytes_per_env_step": B,
+                     "avg_launch_us": per * 1e6}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--env", default="stock", choices=["stock", "portfolio"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3 * N_DAYS)
     ap.add_argument("--warmup", type=int, default=N_DAYS)
@@ -106,6 +147,9 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
+    if args.env == "portfolio":
+        assert world == 1, "portfolio side-bench is single-GPU"
+        return bench_portfolio(args, torch, dev)
 
     E, N, K, T = args.envs_per_gpu, N_TICKERS, N_TECH, N_DAYS
     close, tech, risk = synth_panel()

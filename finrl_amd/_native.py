@@ -54,6 +54,23 @@ class StockStatePtrs(C.Structure):
     _fields_ = [("f64", C.c_void_p), ("i32", C.c_void_p)]
 
 
+class PortfolioConfig(C.Structure):
+    _fields_ = [("n_envs", C.c_int32), ("n_tickers", C.c_int32), ("n_tech", C.c_int32),
+                ("n_days", C.c_int32), ("initial_amount", C.c_double)]
+
+
+class PortfolioPanelPtrs(C.Structure):
+    _fields_ = [("gross_ret", C.c_void_p), ("obs_tmpl", C.c_void_p)]
+
+
+PORTFOLIO_F64_FIELDS = ("value", "last_reward")
+PORTFOLIO_I32_FIELDS = ("day",)
+
+
+class PortfolioStatePtrs(C.Structure):
+    _fields_ = [("f64", C.c_void_p), ("i32", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -85,10 +102,23 @@ def lib():
     L.finenv_stock_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.finenv_stock_episode_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.finenv_portfolio_create.argtypes = [C.POINTER(PortfolioConfig), C.POINTER(C.c_void_p)]
+    L.finenv_portfolio_destroy.argtypes = [C.c_void_p]
+    L.finenv_portfolio_destroy.restype = None
+    L.finenv_portfolio_last_error.argtypes = [C.c_void_p]
+    L.finenv_portfolio_last_error.restype = C.c_char_p
+    L.finenv_portfolio_obs_dim.argtypes = [C.c_void_p]
+    L.finenv_portfolio_bind.argtypes = [C.c_void_p, C.POINTER(PortfolioPanelPtrs),
+                                        C.POINTER(PortfolioStatePtrs)]
+    L.finenv_portfolio_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.finenv_portfolio_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                        C.c_void_p]
     if L.finenv_abi_version() != 2:
         raise NativeLibraryError("libfinenv.so ABI version mismatch; rebuild (make -C finrl_amd/csrc)")
     L.finenv_struct_size.argtypes = [C.c_int]
-    for which, cls in enumerate((StockConfig, StockPanelPtrs, StockStatePtrs)):
+    for which, cls in enumerate((StockConfig, StockPanelPtrs, StockStatePtrs, PortfolioConfig,
+                                 PortfolioPanelPtrs, PortfolioStatePtrs)):
         if L.finenv_struct_size(which) != C.sizeof(cls):
             raise NativeLibraryError(
                 f"ABI struct size mismatch for {cls.__name__}: python {C.sizeof(cls)} vs "
@@ -97,13 +127,13 @@ def lib():
     return L
 
 
-def check(code: int, handle=None, what: str = ""):
+def check(code: int, handle=None, what: str = "", kind: str = "stock"):
     if code == FINENV_OK:
         return
     L = lib()
     msg = L.finenv_strerror(code).decode()
     if handle:
-        detail = L.finenv_stock_last_error(handle).decode()
+        detail = getattr(L, f"finenv_{kind}_last_error")(handle).decode()
         if detail:
             msg = f"{msg}: {detail}"
     raise FinenvError(f"{what or 'finenv'} failed ({code}): {msg}")

@@ -31,6 +31,7 @@
 #include <type_traits>
 
 #include "finenv.h"
+#include "finenv_dev.h"
 
 namespace {
 
@@ -80,27 +81,11 @@ struct Params {
 #define STAMP(k) do { } while (0)
 #endif
 
-// base (uniform, SGPR pair) + 32-bit per-lane BYTE offset: lets hipcc use the
-// `global_load/store v, v_off, s[base]` addressing form instead of keeping a 64-bit VGPR
-// address per array alive across the kernel.  Hosts validate that every offset fits 32 bits.
-template <typename T>
-__device__ __forceinline__ T *at(T *base, unsigned idx)
-{
-    return reinterpret_cast<T *>(
-        reinterpret_cast<char *>(const_cast<typename std::remove_const<T>::type *>(base)) +
-        (size_t)(idx * (unsigned)sizeof(T)));
-}
 // per-env state fields: [field][env] blocks (include/finenv.h)
 #define SF(fld) (*at(p.st.f64, (unsigned)(fld) * (unsigned)E + (unsigned)e))
 #define SI(fld) (*at(p.st.i32, (unsigned)(fld) * (unsigned)E + (unsigned)e))
 #define HOLD(i) SI(FINENV_STOCK_I32_FIELDS + (i))
 #define SH0(i) SI(FINENV_STOCK_I32_FIELDS + N + (i))
-
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
 
 __device__ __forceinline__ void ce(int &a, int &b)
 {
@@ -831,6 +816,9 @@ int finenv_struct_size(int which)
     case 0: return (int)sizeof(finenv_stock_config);
     case 1: return (int)sizeof(finenv_stock_panel);
     case 2: return (int)sizeof(finenv_stock_state);
+    case 3: return (int)sizeof(finenv_portfolio_config);
+    case 4: return (int)sizeof(finenv_portfolio_panel);
+    case 5: return (int)sizeof(finenv_portfolio_state);
     default: return FINENV_ERR_INVALID;
     }
 }

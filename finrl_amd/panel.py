@@ -111,3 +111,66 @@ class StockPanel:
 
     def nbytes_device(self):
         return self.T * (8 * self.N + 4 * self.D + 4 + 8)
+
+
+class PortfolioPanel:
+    """Panel for StockPortfolioEnv (env_portfolio.py:105-112, :172-179): per day an N x N
+    covariance matrix (`df["cov_list"]`, one object per row) and K indicator rows; the
+    observation is their vertical stack, independent of per-env state.
+
+    Device layout (include/finenv.h `finenv_portfolio_panel`):
+      gross_ret f64 [T][N]   close[t+1]/close[t] - 1, evaluated elementwise in fp64 (:184)
+      obs_tmpl  f32 [T][D]   D = (N + K) * N
+    """
+
+    def __init__(self, close, cov, tech=None, *, tech_names=None, dates=None, tickers=None):
+        self.close = np.ascontiguousarray(close, dtype=np.float64)
+        T, N = self.close.shape
+        self.cov = np.ascontiguousarray(cov, dtype=np.float64).reshape(T, N, N)
+        if tech is None or np.size(tech) == 0:
+            tech = np.zeros((T, 0, N))
+        self.tech = np.ascontiguousarray(tech, dtype=np.float64).reshape(T, -1, N)
+        self.T, self.N, self.K = T, N, self.tech.shape[1]
+        self.D = (N + self.K) * N
+        self.tech_names = list(tech_names) if tech_names is not None else \
+            [f"tech{k}" for k in range(self.K)]
+        self.dates = list(dates) if dates is not None else list(range(T))
+        self.tickers = list(tickers) if tickers is not None else [f"TIC{i}" for i in range(N)]
+        self._device_cache = {}
+
+    @classmethod
+    def from_dataframe(cls, df, tech_indicator_list):
+        idx = np.asarray(df.index)
+        days, inv = np.unique(idx, return_inverse=True)
+        T = len(days)
+        N = len(df) // T
+        order = np.argsort(inv, kind="stable")
+        col = lambda name: np.asarray(df[name], dtype=np.float64)[order].reshape(T, N)
+        close = col("close")
+        tech = np.stack([col(t) for t in tech_indicator_list], axis=1) if tech_indicator_list \
+            else np.zeros((T, 0, N))
+        covs = np.asarray(df["cov_list"], dtype=object)[order].reshape(T, N)[:, 0]
+        cov = np.stack([np.asarray(c, dtype=np.float64) for c in covs])
+        dates = np.asarray(df["date"])[order].reshape(T, N)[:, 0].tolist() \
+            if "date" in df.columns else None
+        tickers = np.asarray(df["tic"])[order].reshape(T, N)[0].tolist() \
+            if "tic" in df.columns else None
+        return cls(close, cov, tech, tech_names=tech_indicator_list, dates=dates, tickers=tickers)
+
+    def obs_template(self):
+        return np.concatenate([self.cov.reshape(self.T, -1), self.tech.reshape(self.T, -1)],
+                              axis=1).astype(np.float32)
+
+    def gross_returns(self):
+        g = np.zeros((self.T, self.N))
+        g[:-1] = (self.close[1:] / self.close[:-1]) - 1
+        return g
+
+    def to_device(self, device):
+        import torch
+        key = str(device)
+        if key not in self._device_cache:
+            self._device_cache[key] = dict(
+                gross_ret=torch.from_numpy(self.gross_returns()).to(device),
+                obs_tmpl=torch.from_numpy(self.obs_template()).to(device))
+        return self._device_cache[key]

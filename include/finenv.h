@@ -123,7 +123,7 @@ typedef struct finenv_stock finenv_stock;   /* opaque host-side handle */
 
 int         finenv_abi_version(void);
 /* sizeof() of the ABI structs as the library was compiled (0 = finenv_stock_config,
- * 1 = finenv_stock_panel, 2 = finenv_stock_state): lets a foreign-language binding verify its
+ * 1 = finenv_stock_panel, 2 = finenv_stock_state, 3..5 = the finenv_portfolio_* trio): lets a foreign-language binding verify its
  * struct declarations at load time instead of corrupting memory. */
 int         finenv_struct_size(int which);
 const char *finenv_strerror(int code);
@@ -174,6 +174,54 @@ int finenv_stock_step(finenv_stock *h, const float *actions, float *obs, float *
  * out [E][6] f64 = {begin_total_asset, end_total_asset, total_reward, total_cost,
  *                   total_trades, sharpe (NaN if undefined)}. */
 int finenv_stock_episode_stats(finenv_stock *h, double *out, void *stream);
+
+/* =====================================================================================
+ * StockPortfolioEnv (finrl/meta/env_portfolio_allocation/env_portfolio.py:15-261)
+ *   actions [E][N] f32 (portfolio scores; softmax-normalised inside, :225-229)
+ *   obs     [E][D] f32, D = (N + K) * N: the day's N x N covariance rows then K indicator
+ *           rows (:172-179) -- independent of per-env state
+ *   reward  = new portfolio value, unscaled (:196-198)
+ * Per-env state: portfolio_value, last reward (f64), day (i32).
+ * ===================================================================================== */
+#define FINENV_PORTFOLIO_MAX_TICKERS 64
+
+typedef struct finenv_portfolio_config {
+    int32_t n_envs;
+    int32_t n_tickers;            /* stock_dim                                           */
+    int32_t n_tech;               /* len(tech_indicator_list)                            */
+    int32_t n_days;               /* len(df.index.unique()), :127                        */
+    double  initial_amount;       /* :88, restored by reset() (:213)                     */
+} finenv_portfolio_config;
+
+typedef struct finenv_portfolio_panel {
+    const double *gross_ret;      /* [T][N] f64: row t = close[t+1]/close[t] - 1, evaluated
+                                     elementwise in fp64 exactly as :184 (row T-1 unused) */
+    const float  *obs_tmpl;       /* [T][D] f32 observation rows                          */
+} finenv_portfolio_panel;
+
+enum { FINENV_PF_VALUE = 0, FINENV_PF_LAST_REWARD, FINENV_PORTFOLIO_F64_FIELDS };
+enum { FINENV_PI_DAY = 0, FINENV_PORTFOLIO_I32_FIELDS };
+typedef struct finenv_portfolio_state {
+    double  *f64;                 /* [FINENV_PORTFOLIO_F64_FIELDS][E]                     */
+    int32_t *i32;                 /* [FINENV_PORTFOLIO_I32_FIELDS][E]                     */
+} finenv_portfolio_state;
+
+typedef struct finenv_portfolio finenv_portfolio;
+
+int  finenv_portfolio_create(const finenv_portfolio_config *cfg, finenv_portfolio **out);
+void finenv_portfolio_destroy(finenv_portfolio *h);
+const char *finenv_portfolio_last_error(const finenv_portfolio *h);
+int  finenv_portfolio_obs_dim(const finenv_portfolio *h);
+int  finenv_portfolio_bind(finenv_portfolio *h, const finenv_portfolio_panel *panel,
+                           const finenv_portfolio_state *state);
+/* reset() (:202-220) for all envs or those with mask[e] != 0; obs rows of reset envs. */
+int  finenv_portfolio_reset(finenv_portfolio *h, const uint8_t *mask, float *obs_out,
+                            void *stream);
+/* step() (:125-200); weights_out [E][N] f32 or NULL receives the softmax weights
+ * (actions_memory, :168); term_obs / auto_reset as in finenv_stock_step. */
+int  finenv_portfolio_step(finenv_portfolio *h, const float *actions, float *obs, float *reward,
+                           uint8_t *done, float *term_obs, float *weights_out,
+                           int32_t auto_reset, void *stream);
 
 #ifdef __cplusplus
 }
