@@ -303,13 +303,78 @@ PORTFOLIO_SCENARIOS = {
 }
 
 
+# ----------------------------------------------------------------- multi-crypto env
+def run_crypto(name, *, seed, T, N, W, S, lookback=1, initial_capital=1e6, price0=None,
+               gamma=0.99, buy_cost_pct=1e-3, sell_cost_pct=1e-3, act_scale=1.0):
+    """Unmodified reference CryptoEnv (env_multiple_crypto.py), float64 price/tech arrays."""
+    mod = rh.load_multiple_crypto()
+    rng = np.random.default_rng(seed + 3000)
+    if price0 is None:
+        price0 = 10.0 ** rng.uniform(-1, 4.5, N)
+    price = np.asarray(price0) * np.exp(np.cumsum(rng.normal(0, 0.004, (T, N)), axis=0))
+    tech = rng.normal(0, 3000, (T, W))
+    act = (rng.uniform(-1, 1, (S, N)) * act_scale).astype(np.float32)
+    act[rng.random((S, N)) < 0.1] = 0.0
+    env = mod.CryptoEnv({"price_array": price, "tech_array": tech}, lookback=lookback,
+                        initial_capital=initial_capital, buy_cost_pct=buy_cost_pct,
+                        sell_cost_pct=sell_cost_pct, gamma=gamma)
+    rec = dict(obs=[], reward=[], done=[], cash=[], stocks=[], total_asset=[], gamma_return=[],
+               time=[], reset_step=[-1], reset_obs=[np.asarray(env.reset(), dtype=np.float32)])
+    for s in range(S):
+        obs, rew, done, info = env.step(act[s].copy())
+        assert info is None
+        rec["obs"].append(np.asarray(obs, dtype=np.float32))
+        rec["reward"].append(float(rew))
+        rec["done"].append(bool(done))
+        rec["cash"].append(float(env.cash))
+        rec["stocks"].append(np.asarray(env.stocks, dtype=np.float32).copy())
+        rec["total_asset"].append(float(env.total_asset))
+        rec["gamma_return"].append(float(env.gamma_return))
+        rec["time"].append(int(env.time))
+        if done:
+            rec["reset_step"].append(s)
+            rec["reset_obs"].append(np.asarray(env.reset(), dtype=np.float32))
+    out = dict(price=price, tech=tech, actions=act, norm=np.asarray(env.action_norm_vector),
+               cfg_int=np.array([T, N, W, S, lookback], dtype=np.int64),
+               cfg_float=np.array([initial_capital, buy_cost_pct, sell_cost_pct, gamma]),
+               obs=np.stack(rec["obs"]), reward=np.asarray(rec["reward"]),
+               done=np.asarray(rec["done"]), cash=np.asarray(rec["cash"]),
+               stocks=np.stack(rec["stocks"]), total_asset=np.asarray(rec["total_asset"]),
+               gamma_return=np.asarray(rec["gamma_return"]),
+               time=np.asarray(rec["time"], dtype=np.int64),
+               reset_step=np.asarray(rec["reset_step"], dtype=np.int64),
+               reset_obs=np.stack(rec["reset_obs"]),
+               meta=np.array(["variant=O-raw", f"seed={seed}", f"numpy={np.__version__}",
+                              "source=finrl/meta/env_cryptocurrency_trading/"
+                              "env_multiple_crypto.py (unmodified)"]))
+    path = os.path.join(HERE, f"crypto_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB) steps={S} "
+          f"dones={int(np.sum(rec['done']))} final_asset={rec['total_asset'][-1]:.2f}")
+    return out
+
+
+CRYPTO_SCENARIOS = {
+    # 10 pairs x 4 indicators/pair (tutorials/3-Practical/FinRL_MultiCrypto_Trading.py:314,322)
+    "pairs10": dict(seed=41, T=40, N=10, W=40, S=90),
+    "lookback3": dict(seed=42, T=30, N=4, W=8, S=70, lookback=3, initial_capital=1e5,
+                      price0=[30000.0, 2000.0, 0.5, 95.0]),
+    "n1": dict(seed=43, T=20, N=1, W=3, S=45, initial_capital=5e4, price0=[123.4],
+               buy_cost_pct=0.002, sell_cost_pct=0.0005, gamma=0.97),
+    "n9_poor": dict(seed=44, T=25, N=9, W=5, S=60, initial_capital=2e3, act_scale=3.0),
+}
+
+
 def main(argv):
-    names = argv or (list(STOCK_SCENARIOS) + ["portfolio:" + k for k in PORTFOLIO_SCENARIOS])
+    names = argv or (list(STOCK_SCENARIOS) + ["portfolio:" + k for k in PORTFOLIO_SCENARIOS]
+                     + ["crypto:" + k for k in CRYPTO_SCENARIOS])
     for n in names:
         if n in STOCK_SCENARIOS:
             run_stock(n, **STOCK_SCENARIOS[n])
         elif n.startswith("portfolio:") and n[10:] in PORTFOLIO_SCENARIOS:
             run_portfolio(n[10:], **PORTFOLIO_SCENARIOS[n[10:]])
+        elif n.startswith("crypto:") and n[7:] in CRYPTO_SCENARIOS:
+            run_crypto(n[7:], **CRYPTO_SCENARIOS[n[7:]])
         else:
             raise SystemExit(f"unknown scenario {n}")
 
