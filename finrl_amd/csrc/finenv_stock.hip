@@ -819,6 +819,9 @@ int finenv_struct_size(int which)
     case 3: return (int)sizeof(finenv_portfolio_config);
     case 4: return (int)sizeof(finenv_portfolio_panel);
     case 5: return (int)sizeof(finenv_portfolio_state);
+    case 6: return (int)sizeof(finenv_crypto_config);
+    case 7: return (int)sizeof(finenv_crypto_panel);
+    case 8: return (int)sizeof(finenv_crypto_state);
     default: return FINENV_ERR_INVALID;
     }
 }

@@ -123,7 +123,7 @@ typedef struct finenv_stock finenv_stock;   /* opaque host-side handle */
 
 int         finenv_abi_version(void);
 /* sizeof() of the ABI structs as the library was compiled (0 = finenv_stock_config,
- * 1 = finenv_stock_panel, 2 = finenv_stock_state, 3..5 = the finenv_portfolio_* trio): lets a foreign-language binding verify its
+ * 1 = finenv_stock_panel, 2 = finenv_stock_state, 3..5 = the finenv_portfolio_* trio, 6..8 = the finenv_crypto_* trio): lets a foreign-language binding verify its
  * struct declarations at load time instead of corrupting memory. */
 int         finenv_struct_size(int which);
 const char *finenv_strerror(int code);
@@ -222,6 +222,59 @@ int  finenv_portfolio_reset(finenv_portfolio *h, const uint8_t *mask, float *obs
 int  finenv_portfolio_step(finenv_portfolio *h, const float *actions, float *obs, float *reward,
                            uint8_t *done, float *term_obs, float *weights_out,
                            int32_t auto_reset, void *stream);
+
+/* =====================================================================================
+ * CryptoEnv (finrl/meta/env_cryptocurrency_trading/env_multiple_crypto.py:10-111)
+ *   actions [E][N] f32 in [-1,1], scaled per asset by the action normaliser (:63-65, :103-111)
+ *   obs     [E][D] f32, D = 1 + N + W*lookback = [cash*2^-18 | stocks*2^-3 | tech[time-l]*2^-15]
+ *   reward  (delta total asset) * 2^-16; on the last step the discounted return (:83-89)
+ * Contract: price / tech arrays are float64 (as the reference's processors build them);
+ * stocks are float32 (fractional), cash and assets float64.
+ * ===================================================================================== */
+#define FINENV_CRYPTO_MAX_ASSETS 32
+
+typedef struct finenv_crypto_config {
+    int32_t n_envs;
+    int32_t n_assets;             /* crypto_num, :23                                     */
+    int32_t n_tech;               /* tech_array.shape[1]                                 */
+    int32_t n_steps;              /* price_array.shape[0]                                */
+    int32_t lookback;             /* :13                                                 */
+    int32_t reserved0;
+    double  initial_cash;         /* initial_capital, :14-15                             */
+    double  buy_cost_pct;         /* :16                                                 */
+    double  sell_cost_pct;        /* :17                                                 */
+    double  gamma;                /* :19                                                 */
+} finenv_crypto_config;
+
+typedef struct finenv_crypto_panel {
+    const double *price;          /* [T][N] f64                                          */
+    const float  *tech_scaled;    /* [T][W] f32 = float32(tech * 2^-15), :95-97          */
+    const double *norm;           /* [N] action_norm_vector, :103-111 (host-evaluated)    */
+} finenv_crypto_panel;
+
+enum { FINENV_CF_CASH = 0, FINENV_CF_TOTAL_ASSET, FINENV_CF_GAMMA_RETURN,
+       FINENV_CF_EPISODE_RETURN, FINENV_CF_LAST_REWARD, FINENV_CRYPTO_F64_FIELDS };
+enum { FINENV_CI_TIME = 0, FINENV_CRYPTO_I32_FIELDS };
+typedef struct finenv_crypto_state {
+    double  *f64;                 /* [FINENV_CRYPTO_F64_FIELDS][E]                        */
+    int32_t *i32;                 /* [FINENV_CRYPTO_I32_FIELDS][E]                        */
+    float   *stocks;              /* [N][E] f32 holdings (fractional)                     */
+} finenv_crypto_state;
+
+typedef struct finenv_crypto finenv_crypto;
+
+int  finenv_crypto_create(const finenv_crypto_config *cfg, finenv_crypto **out);
+void finenv_crypto_destroy(finenv_crypto *h);
+const char *finenv_crypto_last_error(const finenv_crypto *h);
+int  finenv_crypto_obs_dim(const finenv_crypto *h);
+int  finenv_crypto_bind(finenv_crypto *h, const finenv_crypto_panel *panel,
+                        const finenv_crypto_state *state);
+/* reset() (:48-57); gamma_return is NOT cleared, as in the reference. */
+int  finenv_crypto_reset(finenv_crypto *h, const uint8_t *mask, float *obs_out, void *stream);
+/* step() (:59-90).  The output pointers may address slice t of rollout tensors
+ * [n_steps][E][...]: collecting a rollout needs no extra copy. */
+int  finenv_crypto_step(finenv_crypto *h, const float *actions, float *obs, float *reward,
+                        uint8_t *done, float *term_obs, int32_t auto_reset, void *stream);
 
 #ifdef __cplusplus
 }

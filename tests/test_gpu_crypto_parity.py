@@ -1,0 +1,117 @@
+"""HIP CryptoEnv (through the C ABI) vs the reference fixtures and the CPU oracle: float32
+observations / stocks and float64 cash / assets / rewards compared for exact equality."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NAMES = sorted(os.path.basename(p)[len("crypto_"):-4]
+               for p in glob.glob(os.path.join(GOLDEN, "crypto_*.npz")))
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device visible: GPU tests must run on the MI355X box")
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_crypto_hip_matches_reference_fixture(name):
+    _need_gpu()
+    from finrl_amd.vec_crypto import VecCryptoEnv
+    z = np.load(os.path.join(GOLDEN, f"crypto_{name}.npz"), allow_pickle=False)
+    T, N, W, S, L = z["cfg_int"].tolist()
+    cap, bc, sc, g = z["cfg_float"].tolist()
+    E = 70
+    env = VecCryptoEnv({"price_array": z["price"], "tech_array": z["tech"]}, E, lookback=L,
+                       initial_capital=cap, buy_cost_pct=bc, sell_cost_pct=sc, gamma=g,
+                       auto_reset=False)
+    np.testing.assert_array_equal(env.action_norm_vector, z["norm"])
+    resets = dict(zip(z["reset_step"].tolist(), z["reset_obs"]))
+    obs = env.reset().cpu().numpy()
+    np.testing.assert_array_equal(obs, np.broadcast_to(resets[-1], obs.shape))
+    nd = 0
+    for s in range(S):
+        a = torch.from_numpy(np.broadcast_to(z["actions"][s], (E, N)).copy()).cuda()
+        obs, rew, done, _ = env.step(a)
+        obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        st = env.state_numpy()
+        for e in (0, 63, 64, E - 1):
+            assert bool(done[e]) == bool(z["done"][s]) and st["time"][e] == z["time"][s], (s, e)
+            np.testing.assert_array_equal(st["stocks"][e], z["stocks"][s], err_msg=f"step {s}")
+            assert st["cash"][e] == z["cash"][s], (s, e)
+            assert st["total_asset"][e] == z["total_asset"][s], (s, e)
+            assert st["gamma_return"][e] == z["gamma_return"][s], (s, e)
+            assert st["last_reward"][e] == z["reward"][s], (s, e)
+            assert rew[e] == np.float32(z["reward"][s])
+            np.testing.assert_array_equal(obs[e], z["obs"][s], err_msg=f"obs step {s}")
+        if z["done"][s]:
+            nd += 1
+            obs = env.reset().cpu().numpy()
+            np.testing.assert_array_equal(obs, np.broadcast_to(resets[s], obs.shape))
+    assert nd == 2
+
+
+@pytest.mark.parametrize("cfg", [dict(E=1000, T=40, N=10, W=40, L=1, steps=90),
+                                 dict(E=130, T=25, N=3, W=7, L=3, steps=60),
+                                 dict(E=65, T=16, N=32, W=1, L=2, steps=40),
+                                 dict(E=64, T=12, N=1, W=0, L=1, steps=30)])
+def test_crypto_hip_matches_oracle_random_batch(cfg):
+    _need_gpu()
+    from finrl_amd.vec_crypto import VecCryptoEnv
+    from oracle.crypto import CryptoOracle
+    E, T, N, W, L = cfg["E"], cfg["T"], cfg["N"], cfg["W"], cfg["L"]
+    rng = np.random.default_rng(E + N)
+    price = 10.0 ** rng.uniform(-1, 4.5, N) * np.exp(
+        np.cumsum(rng.normal(0, 0.004, (T, N)), axis=0))
+    tech = rng.normal(0, 3000, (T, W))
+    kw = dict(lookback=L, initial_capital=3e4, buy_cost_pct=0.0012, sell_cost_pct=0.0008,
+              gamma=0.98)
+    orc = CryptoOracle(price, tech, n_envs=E, **kw)
+    env = VecCryptoEnv({"price_array": price, "tech_array": tech}, E, **kw)
+    env.enable_terminal_obs()
+    np.testing.assert_array_equal(env.reset().cpu().numpy(), orc.reset())
+    nd = 0
+    for s in range(cfg["steps"]):
+        a = rng.uniform(-1, 1, (E, N)).astype(np.float32)
+        a[rng.random((E, N)) < 0.1] = 0.0
+        o_obs, o_rew, o_done, o_term = orc.vec_step(a)
+        g_obs, g_rew, g_done, _ = env.step(torch.from_numpy(a).cuda())
+        np.testing.assert_array_equal(g_done.cpu().numpy().astype(bool), o_done)
+        np.testing.assert_array_equal(g_obs.cpu().numpy(), o_obs, err_msg=f"obs step {s}")
+        np.testing.assert_array_equal(g_rew.cpu().numpy(), o_rew.astype(np.float32))
+        st, os_ = env.state_numpy(), orc.state()
+        for k in ("cash", "total_asset", "gamma_return", "episode_return", "time", "stocks"):
+            np.testing.assert_array_equal(st[k], os_[k], err_msg=f"{k} step {s}")
+        if o_done.any():
+            nd += 1
+            np.testing.assert_array_equal(env.term_obs.cpu().numpy()[o_done], o_term[o_done])
+    assert nd >= 2
+
+
+def test_crypto_rollout_slices_need_no_copy():
+    """Outputs written straight into slice t of [n_steps, E, ...] rollout tensors."""
+    _need_gpu()
+    from finrl_amd.vec_crypto import VecCryptoEnv
+    from oracle.crypto import CryptoOracle
+    E, T, N, W, n_steps = 256, 50, 10, 40, 8
+    rng = np.random.default_rng(3)
+    price = 100 * np.exp(np.cumsum(rng.normal(0, 0.004, (T, N)), axis=0))
+    tech = rng.normal(0, 3000, (T, W))
+    env = VecCryptoEnv({"price_array": price, "tech_array": tech}, E)
+    orc = CryptoOracle(price, tech, n_envs=E)
+    env.reset(); orc.reset()
+    obs_buf = torch.zeros(n_steps, E, env.obs_dim, device="cuda")
+    rew_buf = torch.zeros(n_steps, E, device="cuda")
+    done_buf = torch.zeros(n_steps, E, dtype=torch.uint8, device="cuda")
+    acts = rng.uniform(-1, 1, (n_steps, E, N)).astype(np.float32)
+    for t in range(n_steps):
+        env.step(torch.from_numpy(acts[t]).cuda(), out=(obs_buf[t], rew_buf[t], done_buf[t]))
+    for t in range(n_steps):
+        o_obs, o_rew, o_done, _ = orc.vec_step(acts[t])
+        np.testing.assert_array_equal(obs_buf[t].cpu().numpy(), o_obs)
+        np.testing.assert_array_equal(rew_buf[t].cpu().numpy(), o_rew.astype(np.float32))
