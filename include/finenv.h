@@ -276,6 +276,21 @@ int  finenv_crypto_reset(finenv_crypto *h, const uint8_t *mask, float *obs_out, 
 int  finenv_crypto_step(finenv_crypto *h, const float *actions, float *obs, float *reward,
                         uint8_t *done, float *term_obs, int32_t auto_reset, void *stream);
 
+/* =====================================================================================
+ * Rollout helper (caller side of the path): generalized advantage estimation
+ * over device-resident rollout tensors [n_steps][E], time-reverse scan, one lane per env.
+ * Arithmetic follows stable-baselines3's documented RolloutBuffer.compute_returns_and_advantage
+ * in float32 (SB3 is not vendored in the reference: parity unpinned, defined against the
+ * documented formula):
+ *   nnt_t   = 1 - dones[t]                 (dones[t] = done flag returned by step t)
+ *   delta_t = rewards[t] + gamma * V_{t+1} * nnt_t - values[t],  V_{n} = last_values
+ *   A_t     = delta_t + gamma * lam * nnt_t * A_{t+1};   returns_t = A_t + values[t]
+ * ===================================================================================== */
+int finenv_gae_scan(const float *rewards, const float *values, const uint8_t *dones,
+                    const float *last_values, float *advantages, float *returns,
+                    int32_t n_steps, int32_t n_envs, float gamma, float gae_lambda,
+                    void *stream);
+
 #ifdef __cplusplus
 }
 #endif

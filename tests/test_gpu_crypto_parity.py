@@ -115,3 +115,43 @@ def test_crypto_rollout_slices_need_no_copy():
         o_obs, o_rew, o_done, _ = orc.vec_step(acts[t])
         np.testing.assert_array_equal(obs_buf[t].cpu().numpy(), o_obs)
         np.testing.assert_array_equal(rew_buf[t].cpu().numpy(), o_rew.astype(np.float32))
+
+
+def test_rollout_buffer_and_gae_scan():
+    """Rollout collection straight into [n_steps, E, ...] tensors + GAE scan kernel vs the
+    NumPy restatement of SB3's documented formula (float32, exact)."""
+    _need_gpu()
+    from finrl_amd.rollout import RolloutBuffer
+    from finrl_amd.vec_crypto import VecCryptoEnv
+    from oracle.crypto import CryptoOracle
+    from oracle.gae import gae
+    E, T, N, W, n_steps = 300, 20, 10, 40, 40
+    rng = np.random.default_rng(5)
+    price = 100 * np.exp(np.cumsum(rng.normal(0, 0.004, (T, N)), axis=0))
+    tech = rng.normal(0, 3000, (T, W))
+    env = VecCryptoEnv({"price_array": price, "tech_array": tech}, E)
+    orc = CryptoOracle(price, tech, n_envs=E)
+    buf = RolloutBuffer(n_steps, E, env.obs_dim, N)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(0)
+
+    def policy(obs):
+        a = torch.rand(E, N, generator=gen, device="cuda") * 2 - 1
+        return a, obs[:, 0] * 0.5 + a.sum(1) * 0.01, -a.abs().sum(1)
+
+    first = env.reset()
+    orc.reset()
+    last_obs = buf.collect(env, policy, first)
+    acts = buf.actions.cpu().numpy()
+    for t in range(n_steps):                      # crosses two episode boundaries (auto-reset)
+        o_obs, o_rew, o_done, _ = orc.vec_step(acts[t])
+        np.testing.assert_array_equal(buf.obs[t + 1].cpu().numpy(), o_obs)
+        np.testing.assert_array_equal(buf.rewards[t].cpu().numpy(), o_rew.astype(np.float32))
+        np.testing.assert_array_equal(buf.dones[t].cpu().numpy().astype(bool), o_done)
+    assert buf.dones.sum().item() >= 2 * E
+    last_values = last_obs[:, 0] * 0.5
+    adv, ret = buf.compute_returns_and_advantage(last_values, 0.99, 0.95)
+    e_adv, e_ret = gae(buf.rewards.cpu().numpy(), buf.values.cpu().numpy(),
+                       buf.dones.cpu().numpy(), last_values.cpu().numpy(), 0.99, 0.95)
+    np.testing.assert_array_equal(adv.cpu().numpy(), e_adv)
+    np.testing.assert_array_equal(ret.cpu().numpy(), e_ret)
