@@ -365,14 +365,105 @@ CRYPTO_SCENARIOS = {
 }
 
 
+# ----------------------------------------------------------------- array-state stock env (_np)
+_TAG = {float: 0, np.float32: 1, np.float64: 2}
+
+
+def _tag(x):
+    return _TAG[type(x)] if type(x) in _TAG else {"float32": 1, "float64": 2}[np.asarray(x).dtype.name]
+
+
+def run_stocknp(name, *, seed, T, N, K, S, if_train=False, initial_capital=1e6, max_stock=1e2,
+                turb_scale=60.0, buy_cost_pct=1e-3, sell_cost_pct=1e-3, gamma=0.99):
+    """Unmodified reference env_stocktrading_np.StockTradingEnv (NumPy-version dependent mixed
+    float32/float64 arithmetic: the dtype of every scalar is recorded next to its value)."""
+    mod = rh.load_stocktrading_np()
+    rng = np.random.default_rng(seed + 4000)
+    price = 100 * np.exp(np.cumsum(rng.normal(0, 0.01, (T, N)), axis=0))
+    tech = rng.normal(0, 50, (T, N * K))
+    turb = np.abs(rng.normal(0, turb_scale, T))
+    cfg = {"price_array": price, "tech_array": tech, "turbulence_array": turb,
+           "if_train": if_train}
+    env = mod.StockTradingEnv(cfg, initial_capital=initial_capital, max_stock=max_stock,
+                              buy_cost_pct=buy_cost_pct, sell_cost_pct=sell_cost_pct, gamma=gamma)
+    act = rng.uniform(-1, 1, (S, N)).astype(np.float32)
+    rec = {k: [] for k in ("obs", "reward", "reward_tag", "done", "amount", "amount_tag",
+                           "total_asset", "ta_tag", "gamma_reward", "g_tag", "stocks",
+                           "cool_down", "day", "episode_return")}
+    resets = dict(step=[], obs=[], stocks0=[], amount0=[], amount0_tag=[])
+
+    def do_reset(s):
+        if if_train:
+            mod.rd.seed(seed * 1000 + s + 7)
+        o = env.reset()
+        resets["step"].append(s)
+        resets["obs"].append(np.asarray(o, np.float32))
+        resets["stocks0"].append(np.asarray(env.stocks, np.float32).copy())
+        resets["amount0"].append(float(env.amount))
+        resets["amount0_tag"].append(_tag(env.amount))
+
+    do_reset(-1)
+    for s in range(S):
+        obs, rew, done, info = env.step(act[s].copy())
+        rec["obs"].append(np.asarray(obs, np.float32))
+        rec["reward"].append(float(rew)); rec["reward_tag"].append(_tag(rew))
+        rec["done"].append(bool(done))
+        rec["amount"].append(float(env.amount)); rec["amount_tag"].append(_tag(env.amount))
+        rec["total_asset"].append(float(env.total_asset)); rec["ta_tag"].append(_tag(env.total_asset))
+        rec["gamma_reward"].append(float(env.gamma_reward)); rec["g_tag"].append(_tag(env.gamma_reward))
+        rec["stocks"].append(np.asarray(env.stocks, np.float32).copy())
+        rec["cool_down"].append(np.asarray(env.stocks_cool_down, np.float32).copy())
+        rec["day"].append(int(env.day))
+        rec["episode_return"].append(float(env.episode_return))
+        if done:
+            do_reset(s)
+    out = dict(price_array=price, tech_array=tech, turbulence_array=turb, actions=act,
+               cfg_int=np.array([T, N, K, S, int(if_train)], dtype=np.int64),
+               cfg_float=np.array([initial_capital, max_stock, buy_cost_pct, sell_cost_pct, gamma]),
+               obs=np.stack(rec["obs"]), done=np.asarray(rec["done"]),
+               stocks=np.stack(rec["stocks"]), cool_down=np.stack(rec["cool_down"]),
+               day=np.asarray(rec["day"], np.int64),
+               reset_step=np.asarray(resets["step"], np.int64), reset_obs=np.stack(resets["obs"]),
+               reset_stocks0=np.stack(resets["stocks0"]),
+               reset_amount0=np.asarray(resets["amount0"]),
+               reset_amount0_tag=np.asarray(resets["amount0_tag"], np.int64),
+               meta=np.array(["variant=O-raw", f"seed={seed}", f"numpy={np.__version__}",
+                              "dtype tags: 0=python float, 1=float32, 2=float64",
+                              "source=finrl/meta/env_stock_trading/env_stocktrading_np.py "
+                              "(unmodified)"]))
+    for k in ("reward", "amount", "total_asset", "gamma_reward", "episode_return"):
+        out[k] = np.asarray(rec[k], np.float64)
+    for k in ("reward_tag", "amount_tag", "ta_tag", "g_tag"):
+        out[k] = np.asarray(rec[k], np.int64)
+    path = os.path.join(HERE, f"stocknp_{name}.npz")
+    np.savez_compressed(path, **out)
+    tags = sorted(set(rec["amount_tag"]))
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB) steps={S} "
+          f"dones={int(np.sum(rec['done']))} amount dtypes seen={tags} "
+          f"turbulent days={int((turb > 99).sum())}")
+    return out
+
+
+STOCKNP_SCENARIOS = {
+    "eval_dow30": dict(seed=51, T=40, N=30, K=8, S=95),
+    "eval_poor": dict(seed=52, T=30, N=30, K=8, S=70, initial_capital=3e4),
+    "train_dow30": dict(seed=53, T=30, N=30, K=8, S=70, if_train=True),
+    "eval_n3": dict(seed=54, T=25, N=3, K=2, S=60, initial_capital=5e3, max_stock=50.0,
+                    buy_cost_pct=0.002, sell_cost_pct=0.0005, gamma=0.97, turb_scale=90.0),
+}
+
+
 def main(argv):
     names = argv or (list(STOCK_SCENARIOS) + ["portfolio:" + k for k in PORTFOLIO_SCENARIOS]
-                     + ["crypto:" + k for k in CRYPTO_SCENARIOS])
+                     + ["crypto:" + k for k in CRYPTO_SCENARIOS]
+                     + ["stocknp:" + k for k in STOCKNP_SCENARIOS])
     for n in names:
         if n in STOCK_SCENARIOS:
             run_stock(n, **STOCK_SCENARIOS[n])
         elif n.startswith("portfolio:") and n[10:] in PORTFOLIO_SCENARIOS:
             run_portfolio(n[10:], **PORTFOLIO_SCENARIOS[n[10:]])
+        elif n.startswith("stocknp:") and n[8:] in STOCKNP_SCENARIOS:
+            run_stocknp(n[8:], **STOCKNP_SCENARIOS[n[8:]])
         elif n.startswith("crypto:") and n[7:] in CRYPTO_SCENARIOS:
             run_crypto(n[7:], **CRYPTO_SCENARIOS[n[7:]])
         else:
