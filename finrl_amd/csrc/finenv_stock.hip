@@ -822,6 +822,9 @@ int finenv_struct_size(int which)
     case 6: return (int)sizeof(finenv_crypto_config);
     case 7: return (int)sizeof(finenv_crypto_panel);
     case 8: return (int)sizeof(finenv_crypto_state);
+    case 9: return (int)sizeof(finenv_stocknp_config);
+    case 10: return (int)sizeof(finenv_stocknp_panel);
+    case 11: return (int)sizeof(finenv_stocknp_state);
     default: return FINENV_ERR_INVALID;
     }
 }

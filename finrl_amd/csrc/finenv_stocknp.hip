@@ -1,0 +1,448 @@
+// finenv_stocknp.hip -- MI355X (gfx950) kernel + C ABI for the batched array-state
+// StockTradingEnv (finrl/meta/env_stock_trading/env_stocktrading_np.py).
+//
+// lane = env, one wave per 64 envs, four independent waves per block.  Trades run in ticker
+// index order (this env does not sort), serial through `amount`.  The arithmetic reproduces
+// the reference under NumPy >= 2 bit for bit: amount / total_asset / gamma_reward carry a
+// per-env dtype tag (python float / float32 / float64) and every operation is evaluated in
+// the dtype NumPy's promotion rules pick (see include/finenv.h and oracle/stocknp_oracle.c).
+// HBM-bound: 1993 algorithmic bytes per env-step at DOW30 x 8 (obs row 1332 B).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "finenv.h"
+#include "finenv_dev.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kMaxN = FINENV_STOCKNP_MAX_TICKERS;
+constexpr int kRowA = kMaxN + 1;                       // action rows, stride 33
+constexpr int kRowH = 2 * kMaxN + 1;                   // obs heads [amount|stocks|cool], stride 65
+constexpr int kWaves = 4;
+constexpr int kLdsPerWave = kWave * kRowH + 2 * kMaxN * kWave;   // heads/actions + stocks + cool
+
+struct NpParams {
+    finenv_stocknp_config cfg;
+    finenv_stocknp_panel panel;
+    finenv_stocknp_state st;
+    const float *actions;
+    float *obs;
+    float *reward;
+    uint8_t *done;
+    float *term_obs;
+    const uint8_t *mask;
+    int32_t auto_reset;
+    int32_t D;
+    uint32_t magicN;
+};
+
+#define NF(fld) (*at(p.st.f64, (unsigned)(fld) * (unsigned)E + (unsigned)e))
+#define NI(fld) (*at(p.st.i32, (unsigned)(fld) * (unsigned)E + (unsigned)e))
+#define NS(k, i) (*at(p.st.f32, ((unsigned)(k) * (unsigned)N + (unsigned)(i)) * (unsigned)E + (unsigned)e))
+
+struct Num { double v; int tag; };
+__device__ __forceinline__ Num mk(double v, int tag) { Num r; r.v = v; r.tag = tag; return r; }
+__device__ __forceinline__ int promote(int a, int b)
+{
+    return a == FINENV_NT_PY ? b : (b == FINENV_NT_PY ? a : max(a, b));
+}
+__device__ __forceinline__ Num n_add(Num a, Num b)
+{
+    const int t = promote(a.tag, b.tag);
+    const double r32 = (double)((float)a.v + (float)b.v), r64 = a.v + b.v;
+    return mk(t == FINENV_NT_F32 ? r32 : r64, t);
+}
+__device__ __forceinline__ Num n_sub(Num a, Num b)
+{
+    const int t = promote(a.tag, b.tag);
+    const double r32 = (double)((float)a.v - (float)b.v), r64 = a.v - b.v;
+    return mk(t == FINENV_NT_F32 ? r32 : r64, t);
+}
+__device__ __forceinline__ Num n_mul(Num a, Num b)
+{
+    const int t = promote(a.tag, b.tag);
+    const double r32 = (double)((float)a.v * (float)b.v), r64 = a.v * b.v;
+    return mk(t == FINENV_NT_F32 ? r32 : r64, t);
+}
+__device__ __forceinline__ Num n_div(Num a, Num b)
+{
+    const int t = promote(a.tag, b.tag);
+    const double r32 = (double)((float)a.v / (float)b.v), r64 = a.v / b.v;
+    return mk(t == FINENV_NT_F32 ? r32 : r64, t);
+}
+// exact floor(a/d) for d > 0 (== numpy floor_divide in float64 and, for float32 operands,
+// == npy_floor_dividef: both return the true floor at these magnitudes)
+__device__ __forceinline__ double floordiv_true(double a, double d)
+{
+    double x = __builtin_amdgcn_rcp(d);
+    x = fma(fma(-d, x, 1.0), x, x);
+    double q = floor(a * x);
+    double r = fma(-q, d, a);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        q += (r < 0.0) ? -1.0 : ((r >= d) ? 1.0 : 0.0);
+        r = fma(-q, d, a);
+    }
+    return q;
+}
+__device__ __forceinline__ Num n_floordiv(Num a, Num b)      // b > 0
+{
+    const int t = promote(a.tag, b.tag);
+    // float32 case: operands are first rounded to float32, the quotient is exact in fp64
+    const double av = (t == FINENV_NT_F32) ? (double)(float)a.v : a.v;
+    return mk(floordiv_true(av, b.v), t);
+}
+
+// heads[el*kRowH + 0] = amount*2^-12 (f32), [1..N] stocks*2^-6, [1+N..2N] cool_down
+__device__ __forceinline__ void np_write_rows(float *__restrict__ dst, const NpParams &p, int e0,
+                                              int nenv_w, int row_day,
+                                              unsigned long long lane_mask, const float *heads,
+                                              int lane)
+{
+    if (lane_mask == 0ull) return;
+    const int N = p.cfg.n_tickers, D = p.D;
+    const int first = __builtin_ctzll(lane_mask);
+    const int d0 = __builtin_amdgcn_readlane(row_day, first);
+    const bool mine = (lane_mask >> lane) & 1ull;
+    const bool uniform = __all(!mine || row_day == d0);
+    float *const base = dst + (size_t)e0 * D;
+    const int nchunk = (D + kWave - 1) / kWave;
+    for (int k = 0; k < nchunk; ++k) {
+        const int col = k * kWave + lane;
+        const bool in = col < D;
+        const int hidx = col - 3 - N;                        // stocks then cool_down
+        const bool patch = in && (col == 0 || (hidx >= 0 && hidx < 2 * N));
+        const int sel = (col == 0) ? 0 : (patch ? 1 + hidx : 0);
+        const bool any_patch = __any(patch);
+        float t = 0.0f;
+        if (uniform && in) t = *at(p.panel.obs_tmpl, (unsigned)(d0 * D + col));
+        for (int el = 0; el < nenv_w; ++el) {
+            if (!((lane_mask >> el) & 1ull)) continue;
+            float v = t;
+            if (!uniform) {
+                const int de = __builtin_amdgcn_readlane(row_day, el);
+                if (in) v = *at(p.panel.obs_tmpl, (unsigned)(de * D + col));
+            }
+            if (any_patch) {
+                const float hv = heads[el * kRowH + sel];
+                v = patch ? hv : v;
+            }
+            if (in) *at(base, (unsigned)(el * D + col)) = v;
+        }
+    }
+}
+
+// (stocks * price).sum() in float32, NumPy pairwise order (8 accumulators, n < 128)
+__device__ __forceinline__ float holdings_value(const float *scol, const float *__restrict__ price,
+                                                unsigned pb, int N)
+{
+    auto prod = [&](int i) { return scol[i * kWave] * *at(price, pb + (unsigned)i); };
+    float sum;
+    if (N < 8) {
+        sum = 0.0f;
+        for (int i = 0; i < N; ++i) sum += prod(i);
+    } else {
+        float r8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r8[j] = prod(j);
+        const int full = N - (N & 7);
+        for (int i = 8; i < full; i += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r8[j] += prod(i + j);
+        }
+        sum = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+        for (int i = full; i < N; ++i) sum += prod(i);
+    }
+    return sum;
+}
+
+template <bool RESET_ONLY>
+__global__ void __launch_bounds__(kWave *kWaves) stocknp_kernel(const NpParams p)
+{
+    __shared__ float lds_all[kWaves * kLdsPerWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib = threadIdx.x >> 6;
+    float *heads = lds_all + wib * kLdsPerWave;            // [env][kRowH] (actions use stride kRowA)
+    float *stk = heads + kWave * kRowH;                    // [ticker][lane]
+    float *cdl = stk + kMaxN * kWave;                      // [ticker][lane]
+    const int E = p.cfg.n_envs, N = p.cfg.n_tickers;
+    const int e0 = (blockIdx.x * kWaves + wib) * kWave;
+    if (e0 >= E) return;
+    const int nenv_w = min(kWave, E - e0);
+    const bool valid = lane < nenv_w;
+    const int e = valid ? e0 + lane : e0;
+    float *scol = stk + lane, *ccol = cdl + lane;
+    float *head = heads + lane * kRowH;
+
+    // reset(): day 0, start state, total_asset = amount + (stocks*price[0]).sum()  (:80-101)
+    auto do_reset = [&](Num &amount, Num &ta, Num &gr, Num &ita) {
+        for (int i = 0; i < N; ++i) {
+            scol[i * kWave] = NS(2, i);
+            ccol[i * kWave] = 0.0f;
+        }
+        amount = mk(NF(FINENV_NF_AMOUNT0), NI(FINENV_NI_AMOUNT0_TAG));
+        ta = n_add(amount, mk((double)holdings_value(scol, p.panel.price, 0u, N), FINENV_NT_F32));
+        ita = ta;
+        gr = mk(0.0, FINENV_NT_PY);
+    };
+    auto fill_head = [&](Num amount) {
+        head[0] = (float)n_mul(amount, mk(0x1p-12, FINENV_NT_PY)).v;             // :150
+        for (int i = 0; i < N; ++i) {
+            head[1 + i] = scol[i * kWave] * 0x1p-6f;
+            head[1 + N + i] = ccol[i * kWave];
+        }
+    };
+    auto store_state = [&](Num amount, Num ta, Num gr, Num ita, int rtag, int day) {
+        NF(FINENV_NF_AMOUNT) = amount.v;
+        NF(FINENV_NF_TOTAL_ASSET) = ta.v;
+        NF(FINENV_NF_GAMMA_REWARD) = gr.v;
+        NF(FINENV_NF_INITIAL_TOTAL_ASSET) = ita.v;
+        NI(FINENV_NI_TAGS) = amount.tag | (ta.tag << 2) | (gr.tag << 4) | (ita.tag << 6) | (rtag << 8);
+        NI(FINENV_NI_DAY) = day;
+        for (int i = 0; i < N; ++i) {
+            NS(0, i) = scol[i * kWave];
+            NS(1, i) = ccol[i * kWave];
+        }
+    };
+
+    if (RESET_ONLY) {
+        const bool sel = valid && (p.mask == nullptr || p.mask[e] != 0);
+        Num amount, ta, gr, ita;
+        do_reset(amount, ta, gr, ita);
+        if (sel) store_state(amount, ta, gr, ita, (NI(FINENV_NI_TAGS) >> 8) & 3, 0);
+        if (p.obs == nullptr) return;
+        fill_head(amount);
+        wave_sync();
+        np_write_rows(p.obs, p, e0, nenv_w, 0, __ballot(sel), heads, lane);
+        return;
+    }
+
+    // ---- action tile -> LDS rows (stride kRowA inside the heads region) ---------------------
+    {
+        const float *__restrict__ src = p.actions + (size_t)e0 * N;
+        const int total = nenv_w * N;
+        for (int f = lane; f < total; f += kWave) {
+            const int el = (N == 1) ? f : (int)__umulhi((unsigned)f, p.magicN);
+            heads[el * kRowA + (f - el * N)] = *at(src, (unsigned)f);
+        }
+    }
+    const int tags = NI(FINENV_NI_TAGS);
+    Num amount = mk(NF(FINENV_NF_AMOUNT), tags & 3);
+    const Num ta_old = mk(NF(FINENV_NF_TOTAL_ASSET), (tags >> 2) & 3);
+    Num gr = mk(NF(FINENV_NF_GAMMA_REWARD), (tags >> 4) & 3);
+    Num ita = mk(NF(FINENV_NF_INITIAL_TOTAL_ASSET), (tags >> 6) & 3);
+    const int day = NI(FINENV_NI_DAY) + 1;                                        // :106
+    const unsigned pb = (unsigned)(day * N);
+    for (int i = 0; i < N; ++i) {
+        scol[i * kWave] = NS(0, i);
+        ccol[i * kWave] = NS(1, i) + 1.0f;                                        // :108
+    }
+    wave_sync();
+    const float *arow = heads + lane * kRowA;
+    const float ms = (float)p.cfg.max_stock;
+    const Num one_m = mk(1 - p.cfg.sell_cost_pct, FINENV_NT_PY);
+    const Num one_p = mk(1 + p.cfg.buy_cost_pct, FINENV_NT_PY);
+    const bool calm = *at(p.panel.turb_bool, (unsigned)day) == 0.0f;              // :110
+    const int min_action = p.cfg.min_action;
+
+    // sells then buys, ticker index order (:112-129); liquidation when turbulent (:131-134)
+    for (int i = 0; i < N; ++i) {
+        const int a = (int)(arow[i] * ms);                                        // :104
+        const float pr = *at(p.panel.price, pb + (unsigned)i);
+        if (calm && a < -min_action && pr > 0.0f) {
+            const float s = scol[i * kWave];
+            const double want = (double)(-a);
+            const bool is_int = want < (double)s;            // min(stocks, -a) -> -a (np.int64)
+            const double sell = is_int ? want : (double)s;
+            scol[i * kWave] = (float)((double)s - sell);
+            // price(f32) * sell: int64 operand -> float64; float32 operand -> float32
+            const Num t0 = is_int ? mk((double)pr * sell, FINENV_NT_F64)
+                                  : mk((double)(pr * (float)sell), FINENV_NT_F32);
+            amount = n_add(amount, n_mul(t0, one_m));
+            ccol[i * kWave] = 0.0f;
+        }
+    }
+    for (int i = 0; i < N; ++i) {
+        const int a = (int)(arow[i] * ms);
+        const float pr = *at(p.panel.price, pb + (unsigned)i);
+        if (calm && a > min_action && pr > 0.0f) {
+            const Num q = n_floordiv(amount, mk((double)pr, FINENV_NT_F32));      // amount // price
+            const bool is_int = (double)a < q.v;             // min(q, a) -> a (np.int64)
+            const double buy = is_int ? (double)a : q.v;
+            const Num t0 = is_int ? mk((double)pr * buy, FINENV_NT_F64)
+                                  : n_mul(mk((double)pr, FINENV_NT_F32), q);
+            const float s = scol[i * kWave];
+            scol[i * kWave] = (float)((double)s + buy);
+            amount = n_sub(amount, n_mul(t0, one_p));
+            ccol[i * kWave] = 0.0f;
+        }
+    }
+    if (!calm) {
+        const Num t0 = mk((double)holdings_value(scol, p.panel.price, pb, N), FINENV_NT_F32);
+        amount = n_add(amount, n_mul(t0, one_m));
+        for (int i = 0; i < N; ++i) {
+            scol[i * kWave] = 0.0f;
+            ccol[i * kWave] = 0.0f;
+        }
+    }
+    // total asset, reward, discounted return (:137-145)
+    Num ta = n_add(amount, mk((double)holdings_value(scol, p.panel.price, pb, N), FINENV_NT_F32));
+    Num r = n_mul(n_sub(ta, ta_old), mk(p.cfg.reward_scaling, FINENV_NT_PY));
+    gr = n_add(n_mul(gr, mk(p.cfg.gamma, FINENV_NT_PY)), r);
+    const bool done = day == p.cfg.n_days - 1;
+    if (done) {
+        r = gr;
+        if (valid) NF(FINENV_NF_EPISODE_RETURN) = n_div(ta, ita).v;
+    }
+    if (valid) {
+        *at(p.reward, (unsigned)e) = (float)r.v;
+        *at(p.done, (unsigned)e) = done ? 1 : 0;
+        NF(FINENV_NF_LAST_REWARD) = r.v;
+    }
+    wave_sync();
+    fill_head(amount);                       // overwrites the (consumed) action rows
+    wave_sync();
+    const unsigned long long valid_mask = __ballot(valid);
+    const unsigned long long done_mask = __ballot(done && valid);
+    int row_day = day;
+    if (done_mask != 0ull) {
+        if (p.term_obs != nullptr)
+            np_write_rows(p.term_obs, p, e0, nenv_w, day, done_mask, heads, lane);
+        if (p.auto_reset) {
+            wave_sync();
+            if (done) {
+                do_reset(amount, ta, gr, ita);
+                row_day = 0;
+                fill_head(amount);
+            }
+            wave_sync();
+        }
+    }
+    np_write_rows(p.obs, p, e0, nenv_w, row_day, valid_mask, heads, lane);
+    if (valid) store_state(amount, ta, gr, ita, r.tag, row_day);
+}
+
+}  // namespace
+
+struct finenv_stocknp {
+    finenv_stocknp_config cfg;
+    finenv_stocknp_panel panel;
+    finenv_stocknp_state st;
+    int bound;
+    int D;
+    uint32_t magicN;
+    char err[256];
+};
+
+namespace {
+int np_fail(finenv_stocknp *h, int code, const char *msg)
+{
+    if (h) snprintf(h->err, sizeof(h->err), "%s", msg);
+    return code;
+}
+int np_check(finenv_stocknp *h, const char *what)
+{
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(h->err, sizeof(h->err), "%s: %s", what, hipGetErrorString(e));
+        return FINENV_ERR_HIP;
+    }
+    return FINENV_OK;
+}
+NpParams np_params(const finenv_stocknp *h)
+{
+    NpParams p;
+    memset(&p, 0, sizeof(p));
+    p.cfg = h->cfg;
+    p.panel = h->panel;
+    p.st = h->st;
+    p.D = h->D;
+    p.magicN = h->magicN;
+    return p;
+}
+dim3 np_grid(int E)
+{
+    const int waves = (E + kWave - 1) / kWave;
+    return dim3((unsigned)((waves + kWaves - 1) / kWaves));
+}
+}  // namespace
+
+extern "C" {
+
+int finenv_stocknp_create(const finenv_stocknp_config *cfg, finenv_stocknp **out)
+{
+    if (!cfg || !out) return FINENV_ERR_INVALID;
+    *out = nullptr;
+    if (cfg->n_envs < 1 || cfg->n_tickers < 1 || cfg->n_tickers > FINENV_STOCKNP_MAX_TICKERS ||
+        cfg->n_techw < 0 || cfg->n_days < 2 || cfg->min_action < 0 || cfg->max_stock <= 0 ||
+        cfg->max_stock > 1e6)
+        return FINENV_ERR_INVALID;
+    const long long E = cfg->n_envs, N = cfg->n_tickers, T = cfg->n_days;
+    const long long D = 3 + 3 * N + cfg->n_techw, lim = (1ll << 32) - 1;
+    if (E * 8 * FINENV_STOCKNP_F64_FIELDS > lim || E * N * 12 > lim || T * D * 4 > lim ||
+        64 * D * 4 > lim)
+        return FINENV_ERR_INVALID;
+    finenv_stocknp *h = new (std::nothrow) finenv_stocknp;
+    if (!h) return FINENV_ERR_NOMEM;
+    memset(h, 0, sizeof(*h));
+    h->cfg = *cfg;
+    h->D = (int)D;
+    h->magicN = N >= 2 ? (uint32_t)(((1ull << 32) + N - 1) / (unsigned long long)N) : 0u;
+    *out = h;
+    return FINENV_OK;
+}
+
+void finenv_stocknp_destroy(finenv_stocknp *h) { delete h; }
+const char *finenv_stocknp_last_error(const finenv_stocknp *h) { return h ? h->err : "null handle"; }
+int finenv_stocknp_obs_dim(const finenv_stocknp *h) { return h ? h->D : FINENV_ERR_INVALID; }
+
+int finenv_stocknp_bind(finenv_stocknp *h, const finenv_stocknp_panel *panel,
+                        const finenv_stocknp_state *st)
+{
+    if (!h || !panel || !st) return FINENV_ERR_INVALID;
+    if (!panel->price || !panel->obs_tmpl || !panel->turb_bool || !st->f64 || !st->i32 || !st->f32)
+        return np_fail(h, FINENV_ERR_INVALID, "bind: null pointer");
+    h->panel = *panel;
+    h->st = *st;
+    h->bound = 1;
+    return FINENV_OK;
+}
+
+int finenv_stocknp_reset(finenv_stocknp *h, const uint8_t *mask, float *obs_out, void *stream)
+{
+    if (!h) return FINENV_ERR_INVALID;
+    if (!h->bound) return np_fail(h, FINENV_ERR_UNBOUND, "reset: bind first");
+    NpParams p = np_params(h);
+    p.mask = mask;
+    p.obs = obs_out;
+    hipLaunchKernelGGL((stocknp_kernel<true>), np_grid(h->cfg.n_envs), dim3(kWave * kWaves), 0,
+                       (hipStream_t)stream, p);
+    return np_check(h, "stocknp_reset");
+}
+
+int finenv_stocknp_step(finenv_stocknp *h, const float *actions, float *obs, float *reward,
+                        uint8_t *done, float *term_obs, int32_t auto_reset, void *stream)
+{
+    if (!h) return FINENV_ERR_INVALID;
+    if (!h->bound) return np_fail(h, FINENV_ERR_UNBOUND, "step: bind first");
+    if (!actions || !obs || !reward || !done)
+        return np_fail(h, FINENV_ERR_INVALID, "step: null actions/obs/reward/done");
+    NpParams p = np_params(h);
+    p.actions = actions;
+    p.obs = obs;
+    p.reward = reward;
+    p.done = done;
+    p.term_obs = term_obs;
+    p.auto_reset = auto_reset;
+    hipLaunchKernelGGL((stocknp_kernel<false>), np_grid(h->cfg.n_envs), dim3(kWave * kWaves), 0,
+                       (hipStream_t)stream, p);
+    return np_check(h, "stocknp_step");
+}
+
+}  // extern "C"

@@ -123,7 +123,7 @@ typedef struct finenv_stock finenv_stock;   /* opaque host-side handle */
 
 int         finenv_abi_version(void);
 /* sizeof() of the ABI structs as the library was compiled (0 = finenv_stock_config,
- * 1 = finenv_stock_panel, 2 = finenv_stock_state, 3..5 = the finenv_portfolio_* trio, 6..8 = the finenv_crypto_* trio): lets a foreign-language binding verify its
+ * 1 = finenv_stock_panel, 2 = finenv_stock_state, 3..5 = the finenv_portfolio_* trio, 6..8 = the finenv_crypto_* trio, 9..11 = the finenv_stocknp_* trio): lets a foreign-language binding verify its
  * struct declarations at load time instead of corrupting memory. */
 int         finenv_struct_size(int which);
 const char *finenv_strerror(int code);
@@ -290,6 +290,66 @@ int finenv_gae_scan(const float *rewards, const float *values, const uint8_t *do
                     const float *last_values, float *advantages, float *returns,
                     int32_t n_steps, int32_t n_envs, float gamma, float gae_lambda,
                     void *stream);
+
+/* =====================================================================================
+ * Array-state StockTradingEnv (finrl/meta/env_stock_trading/env_stocktrading_np.py:8-169),
+ * the ElegantRL / RLlib-facing env.
+ *   actions [E][N] f32;  obs [E][D] f32, D = 3 + 3N + W =
+ *     [amount*2^-12 | turbulence_ary[d] | turbulence_bool[d] | price*2^-6 | stocks*2^-6 |
+ *      cool_down | tech_ary[d]]                                               (:149-162)
+ *   reward = delta total_asset * reward_scaling; discounted return on the last step (:137-145)
+ * Numerics: bit-identical to the reference under NumPy >= 2 (NEP 50), where amount /
+ * total_asset / gamma_reward are Python-float, float32 or float64 depending on the trade
+ * history; the dtype of each is tracked per env (FINENV_NT_*, 2 bits each in the `tags` word)
+ * and every operation is performed in the dtype NumPy would use.
+ * ===================================================================================== */
+#define FINENV_STOCKNP_MAX_TICKERS 32
+enum { FINENV_NT_PY = 0, FINENV_NT_F32 = 1, FINENV_NT_F64 = 2 };
+
+typedef struct finenv_stocknp_config {
+    int32_t n_envs;
+    int32_t n_tickers;
+    int32_t n_techw;              /* tech_ary.shape[1] (= N*K, ticker-major)              */
+    int32_t n_days;               /* price_ary.shape[0]; max_step = n_days - 1, :67       */
+    int32_t min_action;           /* int(max_stock * min_stock_rate), :111                */
+    int32_t reserved0;
+    double  max_stock;            /* :39 (action scale, :104)                             */
+    double  buy_cost_pct, sell_cost_pct, reward_scaling, gamma;
+} finenv_stocknp_config;
+
+typedef struct finenv_stocknp_panel {
+    const float *price;           /* [T][N] price_ary (f32), :27                          */
+    const float *obs_tmpl;        /* [T][D] f32 rows: turbulence / price*2^-6 / tech filled,
+                                     amount, stocks and cool_down slots zero              */
+    const float *turb_bool;       /* [T]    (turbulence > thresh) as f32, :32             */
+} finenv_stocknp_panel;
+
+enum { FINENV_NF_AMOUNT = 0, FINENV_NF_TOTAL_ASSET, FINENV_NF_GAMMA_REWARD,
+       FINENV_NF_INITIAL_TOTAL_ASSET, FINENV_NF_EPISODE_RETURN, FINENV_NF_LAST_REWARD,
+       FINENV_NF_AMOUNT0, FINENV_STOCKNP_F64_FIELDS };
+enum { FINENV_NI_DAY = 0, FINENV_NI_TAGS, FINENV_NI_AMOUNT0_TAG, FINENV_STOCKNP_I32_FIELDS };
+/* tags word: bits 0-1 amount, 2-3 total_asset, 4-5 gamma_reward, 6-7 initial_total_asset,
+ * 8-9 last reward */
+typedef struct finenv_stocknp_state {
+    double  *f64;                 /* [FINENV_STOCKNP_F64_FIELDS][E]                       */
+    int32_t *i32;                 /* [FINENV_STOCKNP_I32_FIELDS][E]                       */
+    float   *f32;                 /* [3N][E]: stocks[N], cool_down[N], stocks0[N]          */
+} finenv_stocknp_state;
+
+typedef struct finenv_stocknp finenv_stocknp;
+
+int  finenv_stocknp_create(const finenv_stocknp_config *cfg, finenv_stocknp **out);
+void finenv_stocknp_destroy(finenv_stocknp *h);
+const char *finenv_stocknp_last_error(const finenv_stocknp *h);
+int  finenv_stocknp_obs_dim(const finenv_stocknp *h);
+int  finenv_stocknp_bind(finenv_stocknp *h, const finenv_stocknp_panel *panel,
+                         const finenv_stocknp_state *state);
+/* reset() (:80-101) from the per-env start state (stocks0, amount0, amount0_tag): eval mode =
+ * (initial_stocks, initial_capital as FINENV_NT_PY); train mode = caller-drawn values with
+ * FINENV_NT_F32 (the reference draws them from the global numpy RNG, :85-92). */
+int  finenv_stocknp_reset(finenv_stocknp *h, const uint8_t *mask, float *obs_out, void *stream);
+int  finenv_stocknp_step(finenv_stocknp *h, const float *actions, float *obs, float *reward,
+                         uint8_t *done, float *term_obs, int32_t auto_reset, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,112 @@
+"""HIP array-state StockTradingEnv (through the C ABI) vs the reference fixtures (recorded
+under NumPy 2.2.6) and the CPU oracle: exact equality on float32 obs / stocks / cool-downs, on
+the float64 VALUES of amount / total_asset / gamma_reward / reward and on their NumPy scalar
+dtype tags."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NAMES = sorted(os.path.basename(p)[len("stocknp_"):-4]
+               for p in glob.glob(os.path.join(GOLDEN, "stocknp_*.npz")))
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device visible: GPU tests must run on the MI355X box")
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_stocknp_hip_matches_reference_fixture(name):
+    _need_gpu()
+    from finrl_amd.vec_stocknp import VecStockTradingEnvNP
+    z = np.load(os.path.join(GOLDEN, f"stocknp_{name}.npz"), allow_pickle=False)
+    T, N, K, S, if_train = z["cfg_int"].tolist()
+    cap, ms, bc, sc, g = z["cfg_float"].tolist()
+    E = 70
+    cfg = {"price_array": z["price_array"], "tech_array": z["tech_array"],
+           "turbulence_array": z["turbulence_array"], "if_train": False}
+    env = VecStockTradingEnvNP(cfg, E, gamma=g, max_stock=ms, initial_capital=cap,
+                               buy_cost_pct=bc, sell_cost_pct=sc, auto_reset=False)
+    ri = 0
+
+    def do_reset():
+        nonlocal ri
+        env.set_start_state(z["reset_stocks0"][ri], z["reset_amount0"][ri],
+                            z["reset_amount0_tag"][ri])
+        obs = env.reset().cpu().numpy()
+        np.testing.assert_array_equal(obs, np.broadcast_to(z["reset_obs"][ri], obs.shape))
+        ri += 1
+
+    do_reset()
+    nd = 0
+    for s in range(S):
+        a = torch.from_numpy(np.broadcast_to(z["actions"][s], (E, N)).copy()).cuda()
+        obs, rew, done, _ = env.step(a)
+        obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        st = env.state_numpy()
+        for e in (0, 63, 64, E - 1):
+            assert bool(done[e]) == bool(z["done"][s]) and st["day"][e] == z["day"][s], (s, e)
+            np.testing.assert_array_equal(st["stocks"][e], z["stocks"][s], err_msg=f"step {s}")
+            np.testing.assert_array_equal(st["cool_down"][e], z["cool_down"][s])
+            assert (st["amount"][e], st["amount_tag"][e]) == (z["amount"][s], z["amount_tag"][s]), s
+            assert (st["total_asset"][e], st["ta_tag"][e]) == (z["total_asset"][s], z["ta_tag"][s]), s
+            assert (st["gamma_reward"][e], st["g_tag"][e]) == (z["gamma_reward"][s], z["g_tag"][s]), s
+            assert (st["last_reward"][e], st["reward_tag"][e]) == (z["reward"][s], z["reward_tag"][s]), s
+            assert st["episode_return"][e] == z["episode_return"][s], s
+            assert rew[e] == np.float32(z["reward"][s])
+            np.testing.assert_array_equal(obs[e], z["obs"][s], err_msg=f"obs step {s}")
+        if z["done"][s]:
+            nd += 1
+            do_reset()
+    assert nd == 2
+
+
+@pytest.mark.parametrize("cfg", [dict(E=1000, T=30, N=30, K=8, steps=70, cap=1e6),
+                                 dict(E=130, T=20, N=5, K=2, steps=50, cap=4e3),
+                                 dict(E=65, T=12, N=32, K=1, steps=30, cap=2e5),
+                                 dict(E=64, T=10, N=1, K=0, steps=25, cap=1e3)])
+def test_stocknp_hip_matches_oracle_random_batch(cfg):
+    _need_gpu()
+    from finrl_amd.vec_stocknp import VecStockTradingEnvNP
+    from oracle.stocknp import StockNpOracle
+    E, T, N, K = cfg["E"], cfg["T"], cfg["N"], cfg["K"]
+    rng = np.random.default_rng(E + N)
+    price = 100 * np.exp(np.cumsum(rng.normal(0, 0.01, (T, N)), axis=0))
+    tech = rng.normal(0, 50, (T, N * K))
+    turb = np.abs(rng.normal(0, 70, T))
+    kw = dict(gamma=0.98, initial_capital=cfg["cap"], buy_cost_pct=0.0012, sell_cost_pct=0.0008)
+    orc = StockNpOracle(price, tech, turb, n_envs=E, **kw)
+    env = VecStockTradingEnvNP({"price_array": price, "tech_array": tech,
+                                "turbulence_array": turb, "if_train": False}, E, **kw)
+    env.enable_terminal_obs()
+    # per-env start states, a mix of python-float and float32 amounts (eval / train style)
+    st0 = rng.integers(0, 20, (E, N)).astype(np.float32)
+    tag0 = rng.integers(0, 2, E).astype(np.int32)
+    am0 = np.where(tag0 == 1, (cfg["cap"] * rng.uniform(0.9, 1.1, E)).astype(np.float32),
+                   cfg["cap"] * rng.uniform(0.9, 1.1, E))
+    orc.set_initial(st0, am0, tag0)
+    env.set_start_state(st0, am0, tag0)
+    np.testing.assert_array_equal(env.reset().cpu().numpy(), orc.reset())
+    nd = 0
+    for s in range(cfg["steps"]):
+        a = rng.uniform(-1, 1, (E, N)).astype(np.float32)
+        o_obs, o_rew, o_done, o_term = orc.vec_step(a)
+        g_obs, g_rew, g_done, _ = env.step(torch.from_numpy(a).cuda())
+        np.testing.assert_array_equal(g_done.cpu().numpy().astype(bool), o_done)
+        np.testing.assert_array_equal(g_obs.cpu().numpy(), o_obs, err_msg=f"obs step {s}")
+        np.testing.assert_array_equal(g_rew.cpu().numpy(), o_rew.astype(np.float32))
+        st, os_ = env.state_numpy(), orc.state()
+        for k in ("amount", "amount_tag", "total_asset", "ta_tag", "gamma_reward", "g_tag",
+                  "episode_return", "day", "stocks", "cool_down"):
+            np.testing.assert_array_equal(st[k], os_[k], err_msg=f"{k} step {s}")
+        if o_done.any():
+            nd += 1
+            np.testing.assert_array_equal(env.term_obs.cpu().numpy()[o_done], o_term[o_done])
+    assert nd >= 2
+    assert len(np.unique(env.state_numpy()["amount_tag"])) >= 1
