@@ -320,6 +320,17 @@ stock_step_kernel(const Params p)
 #ifdef FINENV_DIAG
     if (p.dbg != nullptr && lane == 0) p.dbg[((size_t)blockIdx.x * 2 + role) * 16 + 14] = __builtin_amdgcn_s_memtime();
 #endif
+    // ---- both waves: their half of the action tile [nenv_w][N] f32, issued before anything else
+    // (16-B coalesced loads; chunk `it` belongs to wave it & 1) -------------------------------
+    const float *__restrict__ act_src = p.actions + (size_t)e0 * N;          // 16-B aligned
+    const int act_total = nenv_w * N;
+    const int act_n4 = act_total >> 2;
+    float4 av[kNPad / 8];
+#pragma unroll
+    for (int j = 0; j < kNPad / 8; ++j) {
+        const int idx4 = (2 * j + role) * kWave + lane;
+        av[j] = reinterpret_cast<const float4 *>(act_src)[(idx4 < act_n4 && !DIAG(8)) ? idx4 : 0];
+    }
     // ---- both roles: which panel rows this step touches (needs only day / price_day) -----
     int day = SI(FINENV_SI_DAY);
     int pd = SI(FINENV_SI_PRICE_DAY);
@@ -340,39 +351,11 @@ stock_step_kernel(const Params p)
     int hreg[kNPad];
 
     if (role == 1) {
-        // ---- streamer, part 1: stage current price row and the action tile in LDS ---------
+        // ---- streamer, part 1: stage the current price row in LDS ------------------------------
         double pv[kNPad];
 #pragma unroll
         for (int i = 0; i < kNPad; ++i)
             pv[i] = *at(p.panel.close, (unsigned)(pd_cur * N + (i < N ? i : 0)));
-        if (!DIAG(8)) {
-            const float *__restrict__ src = p.actions + (size_t)e0 * N;   // 16-B aligned
-            const int total = nenv_w * N;
-            const int n4 = total >> 2;
-            float4 v[kNPad / 4];
-#pragma unroll
-            for (int it = 0; it < kNPad / 4; ++it) {                      // 8 loads in flight
-                const int j = it * kWave + lane;
-                v[it] = reinterpret_cast<const float4 *>(src)[j < n4 ? j : 0];
-            }
-#pragma unroll
-            for (int it = 0; it < kNPad / 4; ++it) {
-                const int j = it * kWave + lane;
-                if (j < n4) {
-                    const float c[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int f = 4 * j + u;
-                        const int el = (N == 1) ? f : (int)__umulhi((unsigned)f, p.magicN);
-                        lds[el * kRow + (f - el * N)] = c[u];
-                    }
-                }
-            }
-            for (int f = 4 * n4 + lane; f < total; f += kWave) {          // < 4 leftover floats
-                const int el = (N == 1) ? f : (int)__umulhi((unsigned)f, p.magicN);
-                lds[el * kRow + (f - el * N)] = src[f];
-            }
-        }
 #pragma unroll
         for (int i = 0; i < kNPad; ++i) ldsp[i * kWave + lane] = pv[i];
     } else {
@@ -391,6 +374,25 @@ stock_step_kernel(const Params p)
 #pragma unroll
         for (int i = 0; i < kNPad; ++i) hreg[i] = HOLD(i < N ? i : 0);
     }
+    // ---- both waves: transpose their half of the action tile into LDS rows (stride 33) ------
+#pragma unroll
+    for (int j = 0; j < kNPad / 8; ++j) {
+        const int idx4 = (2 * j + role) * kWave + lane;
+        if (idx4 < act_n4) {
+            const float c[4] = {av[j].x, av[j].y, av[j].z, av[j].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = 4 * idx4 + u;
+                const int el = (N == 1) ? f : (int)__umulhi((unsigned)f, p.magicN);
+                lds[el * kRow + (f - el * N)] = c[u];
+            }
+        }
+    }
+    if (role == 1)
+        for (int f = 4 * act_n4 + lane; f < act_total; f += kWave) {          // < 4 leftover floats
+            const int el = (N == 1) ? f : (int)__umulhi((unsigned)f, p.magicN);
+            lds[el * kRow + (f - el * N)] = *at(act_src, (unsigned)f);
+        }
     STAMP(2);
     __syncthreads();
     STAMP(3);
@@ -405,6 +407,13 @@ stock_step_kernel(const Params p)
                            lane, kpatch);
         }
         STAMP(4);
+        // ---- streamer, part 3: once the trader has published the (cash, holdings) rows in LDS,
+        // write the chunk(s) that contain them; the trader goes on to its state write-back.
+        // (Episode-end steps keep that write in the trader: it interleaves with the reset.)
+        __syncthreads();
+        if (!DIAG(1) && term_mask == 0ull)
+            write_obs_rows(p.obs, p.panel.obs_tmpl, D, N, e0, nenv_w, row_obs, valid_mask, rows,
+                           lane, 0, kpatch);
         return;
     }
 
@@ -611,8 +620,10 @@ stock_step_kernel(const Params p)
         }
     }
 
-    // ---- the observation chunk(s) holding cash / holdings (:342 / :453-478) ---------------------
-    if (!DIAG(1))
+    // ---- the observation chunk(s) holding cash / holdings (:342 / :453-478): written by the
+    // streamer after this barrier (rows are final), except on episode-end steps ---------------
+    __syncthreads();
+    if (!DIAG(1) && term_mask != 0ull)
         write_obs_rows(p.obs, p.panel.obs_tmpl, D, N, e0, nenv_w, row_obs, valid_mask, rows, lane,
                        0, kpatch);
     STAMP(10);
