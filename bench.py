@@ -130,6 +130,10 @@ def main():
     ap.add_argument("--desync", action="store_true",
                     help="per-env random start offsets (defeats panel-row broadcast)")
     ap.add_argument("--action-pool", type=int, default=16)
+    ap.add_argument("--tickers", type=int, default=N_TICKERS,
+                    help="30 = DOW30 (headline); 100 = NASDAQ-100 shape (BASELINE configs[3])")
+    ap.add_argument("--turbulence-pct", type=float, default=None,
+                    help="turbulence_threshold = this percentile of the synthetic risk series")
     args = ap.parse_args()
 
     import torch
@@ -151,10 +155,12 @@ def main():
         assert world == 1, "portfolio side-bench is single-GPU"
         return bench_portfolio(args, torch, dev)
 
-    E, N, K, T = args.envs_per_gpu, N_TICKERS, N_TECH, N_DAYS
-    close, tech, risk = synth_panel()
+    E, N, K, T = args.envs_per_gpu, args.tickers, N_TECH, N_DAYS
+    close, tech, risk = synth_panel(N=N)
+    thr = None if args.turbulence_pct is None else float(np.percentile(risk, args.turbulence_pct))
     env = VecStockTradingEnv(StockPanel(close, tech, risk), E, device=dev,
-                             track_stats=not args.no_stats, auto_reset=True, **ENV_KW)
+                             track_stats=not args.no_stats, auto_reset=True,
+                             turbulence_threshold=thr, **ENV_KW)
     env.reset()
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
@@ -211,15 +217,18 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "env-steps/sec at N parallel envs (DOW30, 8 indicators)",
+            "metric": ("env-steps/sec at N parallel envs (DOW30, 8 indicators)" if N == 30 else
+                       f"env-steps/sec at N parallel envs ({N} tickers, 8 indicators)"),
             "value": world * E * args.steps / wall,
             "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{E} vectorized StockTradingEnv per GPU, DOW30 x 8 "
-                                   f"indicators, T={T}, random actions"
+            "config": {"workload": f"{E} vectorized StockTradingEnv per GPU, "
+                                   + ("DOW30" if N == 30 else f"{N} tickers") +
+                                   f" x 8 indicators, T={T}, random actions"
+                                   + (f", turbulence threshold p{args.turbulence_pct:g}" if thr is not None else "")
                                    + (", desynchronised start days" if args.desync else ""),
                        "envs_per_gpu": E, "global_envs": world * E, "tickers": N,
                        "indicators": K, "days": T, "track_stats": not args.no_stats,

@@ -11,7 +11,7 @@ Reference contracts followed:
 Device layout (see include/finenv.h `finenv_stock_panel`):
   close      f64 [T][N]   money arithmetic runs on the reference's own doubles
   obs_tmpl   f32 [T][D]   ready-made observation rows (cash / holdings slots zero)
-  untradable u32 [T]      bit i <=> tech_0[t][i] == 1.0 evaluated in fp64 (:105, :174)
+  untradable u32 [T][W]   bit i <=> tech_0[t][i] == 1.0 evaluated in fp64 (:105, :174)
   risk       f64 [T]
 The whole DOW30 x 8 x 2893-day panel is 4.2 MB: it stays resident in L2 / Infinity Cache,
 so per-step HBM traffic is the per-env state, actions and observations only.
@@ -86,14 +86,16 @@ class StockPanel:
         return out
 
     def untradable_bits(self) -> np.ndarray:
-        """u32 [T]: bit i set iff the first indicator of ticker i equals 1.0 (fp64 compare)."""
-        if self.N > 32:
-            raise ValueError("bitmask form supports N <= 32")
-        bits = np.zeros(self.T, dtype=np.uint32)
+        """u32 [T, W]: bit i (word i // 32) set iff the first indicator of ticker i equals 1.0
+        (fp64 compare).  W = 1 for N <= 32, 4 for N <= 128 (the two kernel variants)."""
+        if self.N > 128:
+            raise ValueError("the stock kernels support N <= 128 tickers")
+        W = 1 if self.N <= 32 else 4
+        bits = np.zeros((self.T, W), dtype=np.uint32)
         if self.K:
             flag = self.tech[:, 0, :] == 1.0
-            w = (np.uint32(1) << np.arange(self.N, dtype=np.uint32))
-            bits = (flag * w[None, :]).sum(axis=1).astype(np.uint32)
+            for i in range(self.N):
+                bits[:, i // 32] |= (flag[:, i].astype(np.uint32) << np.uint32(i % 32))
         return bits
 
     def to_device(self, device):

@@ -46,7 +46,8 @@ enum {
     FINENV_ERR_NOMEM = -4
 };
 
-#define FINENV_STOCK_MAX_TICKERS 32   /* lane-per-env kernel: N <= 32 (DOW30)   */
+#define FINENV_STOCK_MAX_TICKERS 128  /* two kernel variants: N <= 32 (DOW30), N <= 128
+                                         (NASDAQ-100)                               */
 
 /* Constructor arguments of StockTradingEnv that shape the arithmetic
  * (env_stocktrading.py:24-47). */
@@ -55,7 +56,8 @@ typedef struct finenv_stock_config {
     int32_t n_tickers;            /* stock_dim, :50                                      */
     int32_t n_tech;               /* len(tech_indicator_list), :59                       */
     int32_t n_days;               /* len(df.index.unique()), :221                        */
-    int32_t hmax;                 /* :51; |action*hmax| must stay below 2^25             */
+    int32_t hmax;                 /* :51; |action*hmax| must stay below 2^25 (N <= 32) or
+                                     2^23 (N <= 128)                                      */
     int32_t use_turbulence;       /* turbulence_threshold is not None, :68               */
     int32_t reset_quirk;          /* 1: reset() builds obs from the row held before the
                                      rewind (reference behaviour, :361 vs :380-381)      */
@@ -79,7 +81,8 @@ typedef struct finenv_stock_panel {
     const float    *obs_tmpl;     /* [T][D]  f32 observation rows with the cash and
                                      holdings slots zero: f32(close) and f32(tech) in obs
                                      order (what DummyVecEnv's float32 buffer would hold) */
-    const uint32_t *untradable;   /* [T]     bit i set <=> first indicator of ticker i
+    const uint32_t *untradable;   /* [T][W]  W = 1 (N <= 32) or 4 (N <= 128) words per day;
+                                     bit i set <=> first indicator of ticker i
                                      == 1.0 on that day (the fork's `!= True` test,
                                      :105, :174), evaluated on the fp64 values           */
     const double   *risk;         /* [T]     df[risk_indicator_col], :337-341 (may be

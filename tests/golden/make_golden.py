@@ -217,6 +217,10 @@ STOCK_SCENARIOS = {
     "noreset_day3": dict(seed=19, T=16, N=5, K=2, S=30, variant="O-stable", actions="uniform",
                          day0=3, reset_first=False, initial_amount=10_000),
     # longer run, scalars only (no per-step obs): 2+ episodes of 400 days, NASDAQ-ish width
+    # NASDAQ-100 width (128-wide kernel variant), turbulence, flags
+    "n100": dict(seed=21, T=14, N=100, K=2, S=32, variant="O-stable", actions="uniform",
+                 turbulence_threshold=45.0, flag_frac=0.03, initial_amount=400_000,
+                 shares0=np.random.default_rng(8).integers(0, 8, 100)),
     "long": dict(seed=20, T=400, N=30, K=2, S=900, variant="O-stable", actions="uniform",
                  store_obs=False, turbulence_threshold=75.0),
 }

@@ -109,6 +109,10 @@ def _random_panel(seed, T, N, K, flag_frac=0.03):
     dict(E=64, T=12, N=1, K=2, steps=30, thr=30.0, cash=1_000, hmax=10),
     dict(E=257, T=20, N=32, K=1, steps=45, thr=None, cash=100_000, hmax=1000),
     dict(E=65, T=9, N=16, K=0, steps=20, thr=None, cash=30_000, hmax=100),
+    # 128-wide kernel variant (NASDAQ-100 shape and its edges)
+    dict(E=200, T=14, N=100, K=8, steps=32, thr=40.0, cash=400_000, hmax=100),
+    dict(E=70, T=10, N=33, K=1, steps=24, thr=None, cash=50_000, hmax=50),
+    dict(E=64, T=9, N=128, K=1, steps=20, thr=None, cash=900_000, hmax=200),
 ])
 def test_hip_matches_oracle_random_batch(cfg):
     """Distinct action streams per env, DummyVecEnv auto-reset semantics, per-env initial

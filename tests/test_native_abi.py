@@ -49,7 +49,7 @@ def test_create_validates_arguments(L):
     assert L.finenv_stock_step(h, None, None, None, None, None, None, 1, None) == -2
     assert b"bind" in L.finenv_stock_last_error(h)
     L.finenv_stock_destroy(h)
-    for bad in (dict(n_tickers=33), dict(n_tickers=0), dict(n_envs=0), dict(n_days=0),
+    for bad in (dict(n_tickers=129), dict(n_tickers=0), dict(n_envs=0), dict(n_days=0),
                 dict(hmax=-1), dict(n_envs=2**30)):
         cfg = nat.StockConfig(64, 30, 8, 100, 100, 0, 1, 1, 1, 0, 1e-3, 1e-3, 1e-4, 0.0)
         for k, v in bad.items():
