@@ -212,7 +212,8 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("envs_per_gpu") == E and tj.get("kernel") == "stock_step":
+                if tj.get("envs_per_gpu") == E and tj.get("kernel") == "stock_step" and \
+                        tj.get("tickers") == N and thr is None:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
