@@ -25,4 +25,14 @@ __device__ __forceinline__ void wave_sync()
 }
 
 
+
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic (lgkmcnt) but NOT
+// for its outstanding global stores.  __syncthreads() also emits s_waitcnt vmcnt(0), which makes
+// a wave that is streaming stores sit at the barrier until every store has completed (~2 us
+// under load) -- the streamer must keep its stores in flight across the hand-off barriers.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 }  // namespace
