@@ -118,9 +118,58 @@ def bench_portfolio(args, torch, dev):
                      "avg_launch_us": per * 1e6}}), flush=True)
 
 
+def bench_side(args, torch, dev, kind):
+    """Side metrics: multi-crypto env (BASELINE configs[4] shape: 10 pairs x 4 indicators,
+    1-minute bars) and the array-state (_np) stock env, single GPU."""
+    rng = np.random.default_rng(0)
+    E = args.envs_per_gpu
+    if kind == "crypto":
+        from finrl_amd.vec_crypto import VecCryptoEnv
+        T, N, W = 43_200, 10, 40
+        price = 10.0 ** rng.uniform(0, 4.5, N) * np.exp(
+            np.cumsum(rng.normal(0, 0.0005, (T, N)), axis=0))
+        env = VecCryptoEnv({"price_array": price, "tech_array": rng.normal(0, 3000, (T, W))}, E,
+                           device=dev)
+        B = 4 * N + 2 * (28 + 4 * N) + 4 * (1 + N + W) + 5          # SURVEY 8(d): 385
+        name, kern = "vectorized CryptoEnv (10 pairs, 4 indicators/pair)", "crypto_kernel"
+    else:
+        from finrl_amd.vec_stocknp import VecStockTradingEnvNP
+        T, N, K = N_DAYS, N_TICKERS, N_TECH
+        close, tech, risk = synth_panel()
+        env = VecStockTradingEnvNP({"price_array": close, "tech_array": tech.transpose(0, 2, 1)
+                                    .reshape(T, N * K), "turbulence_array": risk * 2,
+                                    "if_train": False}, E, device=dev)
+        B = 4 * N * K + 32 * N + 73                                  # SURVEY 8(d): 1993
+        name, kern = "vectorized array-state StockTradingEnv (DOW30 x 8)", "stocknp_kernel"
+    env.reset()
+    pool = [torch.rand(E, N, device=dev) * 2 - 1 for _ in range(8)]
+    for i in range(args.warmup):
+        env.step(pool[i & 7])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()
+    for i in range(args.steps):
+        env.step(pool[i & 7])
+    e1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    per = e0.elapsed_time(e1) * 1e-3 / args.steps
+    ach = B * E / per / 1e9
+    print(json.dumps({
+        "metric": f"env-steps/sec, {name}", "value": E * args.steps / wall,
+        "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{E} {name}", "envs_per_gpu": E},
+        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": kern,
+                     "bytes_per_env_step": B, "avg_launch_us": per * 1e6}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--env", default="stock", choices=["stock", "portfolio"])
+    ap.add_argument("--env", default="stock", choices=["stock", "portfolio", "crypto", "stocknp"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3 * N_DAYS)
     ap.add_argument("--warmup", type=int, default=N_DAYS)
@@ -154,6 +203,9 @@ def main():
     if args.env == "portfolio":
         assert world == 1, "portfolio side-bench is single-GPU"
         return bench_portfolio(args, torch, dev)
+    if args.env in ("crypto", "stocknp"):
+        assert world == 1, "side benches are single-GPU"
+        return bench_side(args, torch, dev, args.env)
 
     E, N, K, T = args.envs_per_gpu, args.tickers, N_TECH, N_DAYS
     close, tech, risk = synth_panel(N=N)
