@@ -37,6 +37,9 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kStepThreads = 2 * kWave;
+#ifndef FINENV_TRADE_UNROLL
+#define FINENV_TRADE_UNROLL 2     // unroll factor of the rolled sell / buy loops (tuning switch)
+#endif
 
 struct Params {
     finenv_stock_config cfg;
