@@ -1,0 +1,137 @@
+"""Full-size checks at BASELINE.json configs[1] (65,536 envs, DOW30 x 8, T=2893 panel), where
+replaying the oracle for every env would take minutes: size-independent properties plus an
+exact oracle comparison on a sampled subset of envs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+E = 65_536
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device visible: GPU tests must run on the MI355X box")
+
+
+def _panel():
+    import bench
+    return bench.synth_panel()
+
+
+def test_fullsize_properties_and_sampled_oracle():
+    _need_gpu()
+    import bench
+    from finrl_amd import StockPanel
+    from finrl_amd.vec_env import VecStockTradingEnv
+    from oracle.stock import StockOracle
+    close, tech, risk = _panel()
+    T, N = close.shape
+    kw = dict(bench.ENV_KW, turbulence_threshold=float(np.percentile(risk, 90)))
+    env = VecStockTradingEnv(StockPanel(close, tech, risk), E, **kw)
+    env.enable_realised()
+    sample = np.sort(np.random.default_rng(0).choice(E, 192, replace=False))
+    # the sampled envs include both ends and wave / block boundaries
+    sample[:6] = [0, 63, 64, 127, 128, E - 1]
+    sample = np.unique(sample)
+    orc = StockOracle(close, tech, risk, n_envs=len(sample), **kw)
+    obs = env.reset()
+    o_obs = orc.reset()
+    np.testing.assert_array_equal(obs[sample].cpu().numpy(), o_obs.astype(np.float32))
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(7)
+    close_t = torch.from_numpy(close).cuda()
+    prev_asset = env.total_asset().clone()
+    for s in range(60):
+        a = torch.rand(E, N, generator=gen, device="cuda") * 2 - 1
+        day_before = env.state["day"].clone()
+        obs, rew, done, _ = env.step(a)
+        st = env.state
+        # --- properties over all 65,536 envs (device-side, fp64) ---------------------------
+        assert int((st["holdings"] < 0).sum()) == 0, "negative holdings"
+        assert float(st["cash"].min()) >= 0.0, "cash must stay non-negative (cost-aware buys)"
+        assert int(done.sum()) == 0
+        assert torch.equal(st["day"], day_before + 1)
+        # reward == (asset_after - asset_before) * reward_scaling, assets recomputed here
+        asset = st["cash"] + (close_t[st["day"].long()] * st["holdings"].T.double()).sum(1)
+        np.testing.assert_allclose((rew.double() / kw["reward_scaling"]).cpu().numpy(),
+                                   (asset - prev_asset).cpu().numpy(), rtol=0, atol=2.0)
+        prev_asset = asset
+        # realised trades never exceed the request: |realised| <= |trunc(a*hmax)|
+        want = (a * 100.0).to(torch.int32)
+        turb = (st["turbulence"] >= kw["turbulence_threshold"])      # next step's flag
+        real = env.realised
+        ok = (real.abs() <= want.abs()) | (real <= 0)                # liquidation sells exceed
+        assert bool(ok.all())
+        # observation layout: cash | close | holdings | tech
+        assert torch.equal(obs[:, 0], st["cash"].float())
+        assert torch.equal(obs[:, 1 + N:1 + 2 * N], st["holdings"].T.float())
+        # --- exact oracle parity on the sampled envs ---------------------------------------
+        o_obs, o_rew, o_done, _ = orc.vec_step(a[sample].cpu().numpy())
+        np.testing.assert_array_equal(obs[sample].cpu().numpy(), o_obs.astype(np.float32),
+                                      err_msg=f"step {s}")
+        np.testing.assert_array_equal(rew[sample].cpu().numpy(), o_rew.astype(np.float32))
+    os_ = orc.state()
+    np.testing.assert_array_equal(st["cash"][sample].cpu().numpy(), os_["cash"])
+    np.testing.assert_array_equal(st["holdings"].T[sample].cpu().numpy(), os_["shares"])
+
+
+def test_fullsize_identical_envs_agree_and_zero_action_is_idempotent():
+    """All 65,536 envs fed the same actions must stay bit-identical (lane / wave / block
+    invariance); a zero action changes nothing but the day (restated from the reference's
+    tests/environments/test_cash_penalty.py:29-52)."""
+    _need_gpu()
+    import bench
+    from finrl_amd import StockPanel
+    from finrl_amd.vec_env import VecStockTradingEnv
+    close, tech, risk = _panel()
+    N = close.shape[1]
+    env = VecStockTradingEnv(StockPanel(close, tech, risk), E, **bench.ENV_KW)
+    env.reset()
+    rng = np.random.default_rng(3)
+    for s in range(40):
+        row = rng.uniform(-1, 1, N).astype(np.float32) if s % 4 else np.zeros(N, np.float32)
+        a = torch.from_numpy(row).cuda().expand(E, N).contiguous()
+        cash0, hold0 = env.state["cash"].clone(), env.state["holdings"].clone()
+        obs, rew, done, _ = env.step(a)
+        assert bool((obs == obs[0]).all()) and bool((rew == rew[0]).all())
+        assert bool((env.state["cash"] == env.state["cash"][0]).all())
+        if s % 4 == 0:
+            assert torch.equal(env.state["cash"], cash0)
+            assert torch.equal(env.state["holdings"], hold0)
+
+
+def test_fullsize_episode_rollover_checksum():
+    """Run across an episode boundary on a short panel at full batch size: every env resets
+    inside the launch; a checksum of per-env checksums matches the oracle-verified sample."""
+    _need_gpu()
+    import bench
+    from finrl_amd import StockPanel
+    from finrl_amd.vec_env import VecStockTradingEnv
+    from oracle.stock import StockOracle
+    close, tech, risk = _panel()
+    close, tech, risk = close[:12], tech[:12], risk[:12]
+    N = close.shape[1]
+    env = VecStockTradingEnv(StockPanel(close, tech, risk), E, **bench.ENV_KW)
+    env.enable_terminal_obs()
+    sample = np.arange(0, E, 997)
+    orc = StockOracle(close, tech, risk, n_envs=len(sample), **bench.ENV_KW)
+    env.reset(); orc.reset()
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(11)
+    n_done = 0
+    for s in range(30):
+        a = torch.rand(E, N, generator=gen, device="cuda") * 2 - 1
+        obs, rew, done, _ = env.step(a)
+        o_obs, o_rew, o_done, o_term = orc.vec_step(a[sample].cpu().numpy())
+        assert int(done.sum()) in (0, E)                     # lock-step: all or none
+        np.testing.assert_array_equal(obs[sample].cpu().numpy(), o_obs.astype(np.float32))
+        np.testing.assert_array_equal(done[sample].cpu().numpy().astype(bool), o_done)
+        if o_done.all():
+            n_done += 1
+            np.testing.assert_array_equal(env.term_obs[sample].cpu().numpy(),
+                                          o_term.astype(np.float32))
+            assert bool((env.state["day"] == 0).all()) and bool((env.state["trades"] == 0).all())
+    assert n_done == 2
+    assert bool((env.state["episode"] == 3).all())           # initial reset + 2 auto-resets
