@@ -457,15 +457,107 @@ STOCKNP_SCENARIOS = {
 }
 
 
+# ----------------------------------------------------------------- cash-penalty env
+def run_cashpenalty(name, *, seed, T, N, S, cols=("open", "close", "high", "low", "volume"),
+                    hmax=10, initial_amount=1e6, discrete_actions=False, shares_increment=1,
+                    turbulence_threshold=None, patient=False, random_start=False,
+                    cash_penalty_proportion=0.1, buy_cost_pct=3e-3, sell_cost_pct=3e-3,
+                    act_scale=1.0):
+    """Unmodified reference StockTradingEnvCashpenalty on a synthetic OHLCV frame."""
+    import pandas as pd
+    mod = _fresh_cashpenalty()
+    rng = np.random.default_rng(seed + 5000)
+    close = 50 * np.exp(np.cumsum(rng.normal(0, 0.01, (T, N)), axis=0))
+    data = {"open": close * rng.uniform(0.99, 1.01, (T, N)), "close": close,
+            "high": close * 1.01, "low": close * 0.99,
+            "volume": rng.integers(1e5, 1e6, (T, N)).astype(np.float64)}
+    turb = np.abs(rng.normal(0, 30, T))
+    tics = [f"TIC{i:03d}" for i in range(N)]
+    frame = {"date": np.repeat([f"2020-{1 + t // 28:02d}-{1 + t % 28:02d}" for t in range(T)], N),
+             "tic": np.tile(tics, T)}
+    for c in set(cols) | {"close"}:
+        frame[c] = data[c].reshape(-1)
+    frame["turbulence"] = np.repeat(turb, N)
+    df = pd.DataFrame(frame)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        env = mod.StockTradingEnvCashpenalty(
+            df=df, buy_cost_pct=buy_cost_pct, sell_cost_pct=sell_cost_pct, hmax=hmax,
+            discrete_actions=discrete_actions, shares_increment=shares_increment,
+            turbulence_threshold=turbulence_threshold, print_verbosity=10 ** 9,
+            initial_amount=initial_amount, daily_information_cols=list(cols),
+            cache_indicator_data=True, cash_penalty_proportion=cash_penalty_proportion,
+            random_start=random_start, patient=patient)
+        act = (rng.uniform(-1, 1, (S, N)) * act_scale).astype(np.float32)
+        rec = {k: [] for k in ("obs", "reward", "done", "coh", "holdings", "date_index",
+                               "sum_trades")}
+        resets = dict(step=[-1], obs=[np.asarray(env.reset(), np.float64)],
+                      start=[env.starting_point])
+        for s in range(S):
+            obs, rew, done, info = env.step(act[s].copy())
+            rec["obs"].append(np.asarray(obs, np.float64))
+            rec["reward"].append(float(rew)); rec["done"].append(bool(done))
+            rec["coh"].append(float(env.cash_on_hand))
+            rec["holdings"].append(np.asarray(env.holdings, np.float64))
+            rec["date_index"].append(int(env.date_index))
+            rec["sum_trades"].append(float(env.sum_trades))
+            if done:
+                resets["step"].append(s)
+                resets["obs"].append(np.asarray(env.reset(), np.float64))
+                resets["start"].append(env.starting_point)
+    info = np.stack([np.stack([data[c] for c in cols], axis=2)], axis=0)[0]     # [T, N, C]
+    out = dict(close=close, info=info, turb=turb, actions=act,
+               cfg_int=np.array([T, N, len(cols), S, int(discrete_actions), shares_increment,
+                                 int(turbulence_threshold is not None), int(patient)], np.int64),
+               cfg_float=np.array([hmax, buy_cost_pct, sell_cost_pct, initial_amount,
+                                   cash_penalty_proportion,
+                                   turbulence_threshold if turbulence_threshold is not None else 0.0]),
+               obs=np.stack(rec["obs"]), reward=np.asarray(rec["reward"]),
+               done=np.asarray(rec["done"]), coh=np.asarray(rec["coh"]),
+               holdings=np.stack(rec["holdings"]),
+               date_index=np.asarray(rec["date_index"], np.int64),
+               sum_trades=np.asarray(rec["sum_trades"]),
+               reset_step=np.asarray(resets["step"], np.int64), reset_obs=np.stack(resets["obs"]),
+               reset_start=np.asarray(resets["start"], np.int64),
+               meta=np.array(["variant=O-raw", f"seed={seed}", f"numpy={np.__version__}",
+                              "source=finrl/meta/env_stock_trading/"
+                              "env_stocktrading_cashpenalty.py (unmodified)"]))
+    path = os.path.join(HERE, f"cashpenalty_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB) steps={S} "
+          f"dones={int(np.sum(rec['done']))} final_coh={rec['coh'][-1]:.2f}")
+    return out
+
+
+def _fresh_cashpenalty():
+    rh.install()
+    import importlib
+    sys.modules.pop("finrl.meta.env_stock_trading.env_stocktrading_cashpenalty", None)
+    return importlib.import_module("finrl.meta.env_stock_trading.env_stocktrading_cashpenalty")
+
+
+CASHPENALTY_SCENARIOS = {
+    "continuous": dict(seed=61, T=24, N=30, S=60, hmax=20_000, turbulence_threshold=55.0),
+    "shortage": dict(seed=62, T=30, N=5, S=70, hmax=400_000, initial_amount=1e6),
+    "patient": dict(seed=63, T=20, N=5, S=45, hmax=400_000, patient=True, act_scale=1.5),
+    "discrete": dict(seed=64, T=20, N=8, S=45, hmax=30_000, discrete_actions=True,
+                     shares_increment=5, cols=("close", "volume")),
+    "randstart": dict(seed=65, T=30, N=3, S=60, hmax=50_000, random_start=True),
+}
+
+
 def main(argv):
     names = argv or (list(STOCK_SCENARIOS) + ["portfolio:" + k for k in PORTFOLIO_SCENARIOS]
                      + ["crypto:" + k for k in CRYPTO_SCENARIOS]
-                     + ["stocknp:" + k for k in STOCKNP_SCENARIOS])
+                     + ["stocknp:" + k for k in STOCKNP_SCENARIOS]
+                     + ["cashpenalty:" + k for k in CASHPENALTY_SCENARIOS])
     for n in names:
         if n in STOCK_SCENARIOS:
             run_stock(n, **STOCK_SCENARIOS[n])
         elif n.startswith("portfolio:") and n[10:] in PORTFOLIO_SCENARIOS:
             run_portfolio(n[10:], **PORTFOLIO_SCENARIOS[n[10:]])
+        elif n.startswith("cashpenalty:") and n[12:] in CASHPENALTY_SCENARIOS:
+            run_cashpenalty(n[12:], **CASHPENALTY_SCENARIOS[n[12:]])
         elif n.startswith("stocknp:") and n[8:] in STOCKNP_SCENARIOS:
             run_stocknp(n[8:], **STOCKNP_SCENARIOS[n[8:]])
         elif n.startswith("crypto:") and n[7:] in CRYPTO_SCENARIOS:
