@@ -1,0 +1,397 @@
+// finenv_cashpenalty.hip -- MI355X (gfx950) kernel + C ABI for the batched cash-penalty env
+// (finrl/meta/env_stock_trading/env_stocktrading_cashpenalty.py: step :291-372,
+// get_transactions :249-289, get_reward :237-247, reset :131-157).
+//
+// lane = env, one wave per 64 envs.  No ordering between tickers in this env: transactions
+// are computed per ticker (fp64), two dot products give proceeds / spend, one test decides
+// cash shortage; everything is a short fp64 loop per lane plus the observation row write.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "finenv.h"
+#include "finenv_dev.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kMaxN = FINENV_CASHPENALTY_MAX_ASSETS;
+constexpr int kRow = kMaxN + 1;
+constexpr int kWaves = 2;
+constexpr int kLdsPerWave = kWave * kRow + kMaxN * kWave * 2;   // rows + f64 transactions [i][lane]
+
+struct CpParams {
+    finenv_cashpenalty_config cfg;
+    finenv_cashpenalty_panel panel;
+    finenv_cashpenalty_state st;
+    const float *actions;
+    float *obs;
+    float *reward;
+    uint8_t *done;
+    float *term_obs;
+    const uint8_t *mask;
+    int32_t auto_reset;
+    int32_t D;
+    uint32_t magicN;
+};
+
+#define KF(fld) (*at(p.st.f64, (unsigned)(fld) * (unsigned)E + (unsigned)e))
+#define KI(fld) (*at(p.st.i32, (unsigned)(fld) * (unsigned)E + (unsigned)e))
+#define KH(i) KF(FINENV_CASHPENALTY_F64_FIELDS + (i))
+
+__device__ __forceinline__ double cp_floordiv(double a, double d)       // exact floor(a/d), d > 0
+{
+    double x = __builtin_amdgcn_rcp(d);
+    x = fma(fma(-d, x, 1.0), x, x);
+    double q = floor(a * x);
+    double r = fma(-q, d, a);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        q += (r < 0.0) ? -1.0 : ((r >= d) ? 1.0 : 0.0);
+        r = fma(-q, d, a);
+    }
+    return q;
+}
+
+__device__ __forceinline__ double cp_reward(const finenv_cashpenalty_config &c, int step,
+                                            double total, double cash)     // :237-247
+{
+    if (step == 0) return 0.0;
+    const double pen = fmax(0.0, total * c.cash_penalty_proportion - cash);
+    double r = ((total - pen) / c.initial_amount) - 1;
+    r /= (double)step;
+    return r;
+}
+
+// rows[el*kRow + 0] = f32 cash, rows[el*kRow + 1 + i] = f32 holdings_i; columns > N: info row
+__device__ __forceinline__ void cp_write_rows(float *__restrict__ dst, const CpParams &p, int e0,
+                                              int nenv_w, int row_day,
+                                              unsigned long long lane_mask, const float *rows,
+                                              int lane)
+{
+    if (lane_mask == 0ull) return;
+    const int N = p.cfg.n_assets, D = p.D, W = D - 1 - N;
+    const int first = __builtin_ctzll(lane_mask);
+    const int d0 = __builtin_amdgcn_readlane(row_day, first);
+    const bool mine = (lane_mask >> lane) & 1ull;
+    const bool uniform = __all(!mine || row_day == d0);
+    float *const base = dst + (size_t)e0 * D;
+    const int nchunk = (D + kWave - 1) / kWave;
+    for (int k = 0; k < nchunk; ++k) {
+        const int col = k * kWave + lane;
+        const bool in = col < D;
+        const bool head = col <= N;
+        const bool any_head = __any(in && head);
+        float t = 0.0f;
+        if (uniform && in && !head) t = *at(p.panel.info, (unsigned)(d0 * W + col - 1 - N));
+        for (int el = 0; el < nenv_w; ++el) {
+            if (!((lane_mask >> el) & 1ull)) continue;
+            float v = t;
+            if (!uniform) {
+                const int de = __builtin_amdgcn_readlane(row_day, el);
+                if (in && !head) v = *at(p.panel.info, (unsigned)(de * W + col - 1 - N));
+            }
+            if (any_head) {
+                const float hv = rows[el * kRow + (head ? col : 0)];
+                v = head ? hv : v;
+            }
+            if (in) *at(base, (unsigned)(el * D + col)) = v;
+        }
+    }
+}
+
+template <bool RESET_ONLY>
+__global__ void __launch_bounds__(kWave *kWaves) cashpenalty_kernel(const CpParams p)
+{
+    __shared__ __attribute__((aligned(16))) float lds_all[kWaves * kLdsPerWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib = threadIdx.x >> 6;
+    float *rows = lds_all + wib * kLdsPerWave;
+    double *trl = reinterpret_cast<double *>(rows + kWave * kRow + ((kWave * kRow) & 1));
+    const int E = p.cfg.n_envs, N = p.cfg.n_assets;
+    const int e0 = (blockIdx.x * kWaves + wib) * kWave;
+    if (e0 >= E) return;
+    const int nenv_w = min(kWave, E - e0);
+    const bool valid = lane < nenv_w;
+    const int e = valid ? e0 + lane : e0;
+    float *row = rows + lane * kRow;
+    const finenv_cashpenalty_config &c = p.cfg;
+
+    if (RESET_ONLY) {                                                          // :131-157
+        const bool sel = valid && (p.mask == nullptr || p.mask[e] != 0);
+        const int start = KI(FINENV_KI_NEXT_START);
+        if (sel) {
+            KI(FINENV_KI_START) = start;
+            KI(FINENV_KI_DATE_INDEX) = start;
+            KI(FINENV_KI_EPISODE) += 1;
+            KF(FINENV_KF_TURBULENCE) = 0.0;
+            KF(FINENV_KF_SUM_TRADES) = 0.0;
+            KF(FINENV_KF_COH) = c.initial_amount;
+            for (int i = 0; i < N; ++i) KH(i) = 0.0;
+        }
+        if (p.obs == nullptr) return;
+        row[0] = (float)c.initial_amount;
+        for (int i = 0; i < N; ++i) row[1 + i] = 0.0f;
+        wave_sync();
+        cp_write_rows(p.obs, p, e0, nenv_w, start, __ballot(sel), rows, lane);
+        return;
+    }
+
+    // ---- action tile -> LDS rows --------------------------------------------------------------
+    {
+        const float *__restrict__ src = p.actions + (size_t)e0 * N;
+        const int total = nenv_w * N;
+        for (int f = lane; f < total; f += kWave) {
+            const int el = (N == 1) ? f : (int)__umulhi((unsigned)f, p.magicN);
+            rows[el * kRow + (f - el * N)] = *at(src, (unsigned)f);
+        }
+    }
+    int di = KI(FINENV_KI_DATE_INDEX);
+    const int start = KI(FINENV_KI_START);
+    double coh = KF(FINENV_KF_COH);
+    double turb = c.use_turbulence ? KF(FINENV_KF_TURBULENCE) : 0.0;
+    double sum_trades = KF(FINENV_KF_SUM_TRADES);
+    double logged_total = KF(FINENV_KF_LOGGED_TOTAL), logged_cash = KF(FINENV_KF_LOGGED_CASH);
+    const int step = di - start;                                                 // current_step
+    const bool at_end = di == c.n_days - 1;                                      // :299
+    const unsigned cb = (unsigned)(di * N);
+    wave_sync();
+
+    double reward;
+    bool done = at_end;
+    const float hmaxf = (float)c.hmax;
+    const bool turbulent = c.use_turbulence && turb >= c.turbulence_threshold;
+    double asset_value = 0.0, proceeds = 0.0, spend = 0.0;
+    for (int i = 0; i < N; ++i) sum_trades += fabs((double)row[i]);              // :293
+    if (!at_end) {
+        for (int i = 0; i < N; ++i) {
+            const double h = KH(i);
+            const double cl = *at(p.panel.close, cb + (unsigned)i);
+            asset_value += h * cl;                                               // np.dot, :310
+            const float a32 = row[i] * hmaxf;                                    // :257 (float32)
+            const float a = cl > 0.0 ? a32 : 0.0f;                               // :260
+            double tr;
+            if (c.discrete_actions) {                                            // :263-274
+                long long q = (long long)cp_floordiv((double)a, cl);
+                const long long inc = c.shares_increment;
+                const long long num = q >= 0 ? q : q + inc;
+                long long fq = num / inc;
+                if ((num % inc != 0) && ((num < 0) != (inc < 0))) fq -= 1;
+                tr = (double)(fq * inc);
+            } else {
+                tr = (double)a / cl;                                             // :276
+            }
+            tr = fmax(tr, -h);                                                   // :279
+            tr = turbulent ? -h : tr;                                            // :282-287
+            trl[i * kWave + lane] = tr;
+            proceeds += (tr < 0.0 ? -tr : 0.0) * cl;                             // :323-324
+            spend += (tr > 0.0 ? tr : 0.0) * cl;                                 // :328-329
+        }
+        logged_cash = coh;                                                       // :312-314
+        logged_total = coh + asset_value;
+    }
+    reward = cp_reward(c, step, logged_total, logged_cash);                      // :317 / :301
+    bool keep_buys = true;
+    double coh_new = coh;
+    if (!at_end) {
+        double costs = proceeds * c.sell_cost_pct;                               // :325
+        const double coh1 = coh + proceeds;                                      // :326
+        costs += spend * c.buy_cost_pct;                                         // :330
+        if (spend + costs > coh1) {                                              // :333
+            if (c.patient) {                                                     // :334-339
+                keep_buys = false;
+                spend = 0.0;
+                costs = 0.0;
+            } else {
+                done = true;                                                     // :341-344
+            }
+        }
+        coh_new = coh1 - spend - costs;                                          // :351
+    }
+    const bool advance = !done;
+    if (advance) {
+        coh = coh_new;
+        for (int i = 0; i < N; ++i) {
+            const double tr = trl[i * kWave + lane];
+            const double hn = KH(i) + ((tr > 0.0 && !keep_buys) ? 0.0 : tr);     // :352
+            if (valid) KH(i) = hn;
+            row[1 + i] = (float)hn;
+        }
+        di += 1;                                                                 // :353
+        if (c.use_turbulence) turb = *at(p.panel.turb, (unsigned)di);            // :354-357
+    } else {
+        for (int i = 0; i < N; ++i) row[1 + i] = (float)KH(i);
+    }
+    row[0] = (float)coh;
+    if (valid) {
+        *at(p.reward, (unsigned)e) = (float)reward;
+        *at(p.done, (unsigned)e) = done ? 1 : 0;
+        KF(FINENV_KF_SUM_TRADES) = sum_trades;
+        KF(FINENV_KF_LOGGED_TOTAL) = logged_total;
+        KF(FINENV_KF_LOGGED_CASH) = logged_cash;
+    }
+    wave_sync();
+    const unsigned long long valid_mask = __ballot(valid);
+    const unsigned long long done_mask = __ballot(done && valid);
+    int row_day = di;
+    if (done_mask != 0ull) {
+        if (p.term_obs != nullptr)
+            cp_write_rows(p.term_obs, p, e0, nenv_w, di, done_mask, rows, lane);
+        if (p.auto_reset) {                                                      // reset()
+            wave_sync();
+            if (done) {
+                const int ns = KI(FINENV_KI_NEXT_START);
+                di = ns;
+                row_day = ns;
+                coh = c.initial_amount;
+                turb = 0.0;
+                row[0] = (float)coh;
+                for (int i = 0; i < N; ++i) {
+                    if (valid) KH(i) = 0.0;
+                    row[1 + i] = 0.0f;
+                }
+                if (valid) {
+                    KI(FINENV_KI_START) = ns;
+                    KI(FINENV_KI_EPISODE) += 1;
+                    KF(FINENV_KF_SUM_TRADES) = 0.0;
+                }
+            }
+            wave_sync();
+        }
+    }
+    cp_write_rows(p.obs, p, e0, nenv_w, row_day, valid_mask, rows, lane);
+    if (valid) {
+        KF(FINENV_KF_COH) = coh;
+        KI(FINENV_KI_DATE_INDEX) = di;
+        if (c.use_turbulence) KF(FINENV_KF_TURBULENCE) = turb;
+    }
+}
+
+}  // namespace
+
+struct finenv_cashpenalty {
+    finenv_cashpenalty_config cfg;
+    finenv_cashpenalty_panel panel;
+    finenv_cashpenalty_state st;
+    int bound;
+    int D;
+    uint32_t magicN;
+    char err[256];
+};
+
+namespace {
+int kp_fail(finenv_cashpenalty *h, int code, const char *msg)
+{
+    if (h) snprintf(h->err, sizeof(h->err), "%s", msg);
+    return code;
+}
+int kp_check(finenv_cashpenalty *h, const char *what)
+{
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(h->err, sizeof(h->err), "%s: %s", what, hipGetErrorString(e));
+        return FINENV_ERR_HIP;
+    }
+    return FINENV_OK;
+}
+CpParams kp_params(const finenv_cashpenalty *h)
+{
+    CpParams p;
+    memset(&p, 0, sizeof(p));
+    p.cfg = h->cfg;
+    p.panel = h->panel;
+    p.st = h->st;
+    p.D = h->D;
+    p.magicN = h->magicN;
+    return p;
+}
+dim3 kp_grid(int E)
+{
+    const int waves = (E + kWave - 1) / kWave;
+    return dim3((unsigned)((waves + kWaves - 1) / kWaves));
+}
+}  // namespace
+
+extern "C" {
+
+int finenv_cashpenalty_create(const finenv_cashpenalty_config *cfg, finenv_cashpenalty **out)
+{
+    if (!cfg || !out) return FINENV_ERR_INVALID;
+    *out = nullptr;
+    if (cfg->n_envs < 1 || cfg->n_assets < 1 || cfg->n_assets > FINENV_CASHPENALTY_MAX_ASSETS ||
+        cfg->n_cols < 0 || cfg->n_days < 1 || cfg->shares_increment < 1 || !(cfg->hmax >= 0) ||
+        !(cfg->initial_amount > 0))
+        return FINENV_ERR_INVALID;
+    const long long E = cfg->n_envs, N = cfg->n_assets, T = cfg->n_days;
+    const long long D = 1 + N + N * cfg->n_cols, lim = (1ll << 32) - 1;
+    if ((FINENV_CASHPENALTY_F64_FIELDS + N) * E * 8 > lim || T * N * cfg->n_cols * 4 > lim ||
+        T * N * 8 > lim || 64 * D * 4 > lim || E * N * 4 > lim)
+        return FINENV_ERR_INVALID;
+    finenv_cashpenalty *h = new (std::nothrow) finenv_cashpenalty;
+    if (!h) return FINENV_ERR_NOMEM;
+    memset(h, 0, sizeof(*h));
+    h->cfg = *cfg;
+    h->D = (int)D;
+    h->magicN = N >= 2 ? (uint32_t)(((1ull << 32) + N - 1) / (unsigned long long)N) : 0u;
+    *out = h;
+    return FINENV_OK;
+}
+
+void finenv_cashpenalty_destroy(finenv_cashpenalty *h) { delete h; }
+const char *finenv_cashpenalty_last_error(const finenv_cashpenalty *h)
+{
+    return h ? h->err : "null handle";
+}
+int finenv_cashpenalty_obs_dim(const finenv_cashpenalty *h) { return h ? h->D : FINENV_ERR_INVALID; }
+
+int finenv_cashpenalty_bind(finenv_cashpenalty *h, const finenv_cashpenalty_panel *panel,
+                            const finenv_cashpenalty_state *st)
+{
+    if (!h || !panel || !st) return FINENV_ERR_INVALID;
+    if (!panel->close || (!panel->info && h->cfg.n_cols > 0) ||
+        (!panel->turb && h->cfg.use_turbulence) || !st->f64 || !st->i32)
+        return kp_fail(h, FINENV_ERR_INVALID, "bind: null pointer");
+    h->panel = *panel;
+    h->st = *st;
+    h->bound = 1;
+    return FINENV_OK;
+}
+
+int finenv_cashpenalty_reset(finenv_cashpenalty *h, const uint8_t *mask, float *obs_out,
+                             void *stream)
+{
+    if (!h) return FINENV_ERR_INVALID;
+    if (!h->bound) return kp_fail(h, FINENV_ERR_UNBOUND, "reset: bind first");
+    CpParams p = kp_params(h);
+    p.mask = mask;
+    p.obs = obs_out;
+    hipLaunchKernelGGL((cashpenalty_kernel<true>), kp_grid(h->cfg.n_envs), dim3(kWave * kWaves),
+                       0, (hipStream_t)stream, p);
+    return kp_check(h, "cashpenalty_reset");
+}
+
+int finenv_cashpenalty_step(finenv_cashpenalty *h, const float *actions, float *obs,
+                            float *reward, uint8_t *done, float *term_obs, int32_t auto_reset,
+                            void *stream)
+{
+    if (!h) return FINENV_ERR_INVALID;
+    if (!h->bound) return kp_fail(h, FINENV_ERR_UNBOUND, "step: bind first");
+    if (!actions || !obs || !reward || !done)
+        return kp_fail(h, FINENV_ERR_INVALID, "step: null actions/obs/reward/done");
+    CpParams p = kp_params(h);
+    p.actions = actions;
+    p.obs = obs;
+    p.reward = reward;
+    p.done = done;
+    p.term_obs = term_obs;
+    p.auto_reset = auto_reset;
+    hipLaunchKernelGGL((cashpenalty_kernel<false>), kp_grid(h->cfg.n_envs), dim3(kWave * kWaves),
+                       0, (hipStream_t)stream, p);
+    return kp_check(h, "cashpenalty_step");
+}
+
+}  // extern "C"

@@ -252,6 +252,9 @@ int finenv_struct_size(int which)
     case 9: return (int)sizeof(finenv_stocknp_config);
     case 10: return (int)sizeof(finenv_stocknp_panel);
     case 11: return (int)sizeof(finenv_stocknp_state);
+    case 12: return (int)sizeof(finenv_cashpenalty_config);
+    case 13: return (int)sizeof(finenv_cashpenalty_panel);
+    case 14: return (int)sizeof(finenv_cashpenalty_state);
     default: return FINENV_ERR_INVALID;
     }
 }

@@ -126,7 +126,8 @@ typedef struct finenv_stock finenv_stock;   /* opaque host-side handle */
 
 int         finenv_abi_version(void);
 /* sizeof() of the ABI structs as the library was compiled (0 = finenv_stock_config,
- * 1 = finenv_stock_panel, 2 = finenv_stock_state, 3..5 = the finenv_portfolio_* trio, 6..8 = the finenv_crypto_* trio, 9..11 = the finenv_stocknp_* trio): lets a foreign-language binding verify its
+ * 1 = finenv_stock_panel, 2 = finenv_stock_state, 3..5 = the finenv_portfolio_* trio, 6..8 = the finenv_crypto_* trio, 9..11 = the finenv_stocknp_* trio,
+ * 12..14 = the finenv_cashpenalty_* trio): lets a foreign-language binding verify its
  * struct declarations at load time instead of corrupting memory. */
 int         finenv_struct_size(int which);
 const char *finenv_strerror(int code);
@@ -353,6 +354,60 @@ int  finenv_stocknp_bind(finenv_stocknp *h, const finenv_stocknp_panel *panel,
 int  finenv_stocknp_reset(finenv_stocknp *h, const uint8_t *mask, float *obs_out, void *stream);
 int  finenv_stocknp_step(finenv_stocknp *h, const float *actions, float *obs, float *reward,
                          uint8_t *done, float *term_obs, int32_t auto_reset, void *stream);
+
+/* =====================================================================================
+ * StockTradingEnvCashpenalty
+ * (finrl/meta/env_stock_trading/env_stocktrading_cashpenalty.py:19-409): continuous (or
+ * discretised) share counts from dollar-sized actions, no per-ticker ordering, reward =
+ * (assets - cash-shortfall penalty) / initial - 1, per elapsed step (:237-247); episode ends at
+ * the last date or on a cash shortage (unless patient) (:333-344).
+ *   actions [E][N] f32;  obs [E][D] f32, D = 1 + N + N*C = [cash | holdings | info[N][C]]
+ * Contract: close > 0, scalar hmax.  The three dot products per step are summed left to right
+ * (the reference uses BLAS ddot, order unspecified: agreement ~1e-15 relative).
+ * ===================================================================================== */
+#define FINENV_CASHPENALTY_MAX_ASSETS 32
+
+typedef struct finenv_cashpenalty_config {
+    int32_t n_envs, n_assets, n_cols, n_days;
+    int32_t discrete_actions;     /* :60, :263-274                                        */
+    int32_t shares_increment;     /* :61                                                  */
+    int32_t use_turbulence;       /* turbulence_threshold is not None, :282               */
+    int32_t patient;              /* :68, :334-339                                        */
+    double  hmax;                 /* :59 (dollars per trade)                              */
+    double  buy_cost_pct, sell_cost_pct, initial_amount, cash_penalty_proportion,
+            turbulence_threshold;
+} finenv_cashpenalty_config;
+
+typedef struct finenv_cashpenalty_panel {
+    const double *close;          /* [T][N] f64                                           */
+    const float  *info;           /* [T][N*C] f32 date vectors, ticker-major (:159-171)   */
+    const double *turb;           /* [T] f64 (may be NULL when use_turbulence == 0)       */
+} finenv_cashpenalty_panel;
+
+enum { FINENV_KF_COH = 0, FINENV_KF_TURBULENCE, FINENV_KF_SUM_TRADES, FINENV_KF_LOGGED_TOTAL,
+       FINENV_KF_LOGGED_CASH, FINENV_CASHPENALTY_F64_FIELDS /* then holdings[N][E] */ };
+enum { FINENV_KI_DATE_INDEX = 0, FINENV_KI_START, FINENV_KI_EPISODE,
+       FINENV_KI_NEXT_START,      /* starting point the next reset() uses (random_start: the
+                                     caller refills it; the reference draws it with `random`) */
+       FINENV_CASHPENALTY_I32_FIELDS };
+typedef struct finenv_cashpenalty_state {
+    double  *f64;                 /* [FINENV_CASHPENALTY_F64_FIELDS + N][E]                */
+    int32_t *i32;                 /* [FINENV_CASHPENALTY_I32_FIELDS][E]                    */
+} finenv_cashpenalty_state;
+
+typedef struct finenv_cashpenalty finenv_cashpenalty;
+
+int  finenv_cashpenalty_create(const finenv_cashpenalty_config *cfg, finenv_cashpenalty **out);
+void finenv_cashpenalty_destroy(finenv_cashpenalty *h);
+const char *finenv_cashpenalty_last_error(const finenv_cashpenalty *h);
+int  finenv_cashpenalty_obs_dim(const finenv_cashpenalty *h);
+int  finenv_cashpenalty_bind(finenv_cashpenalty *h, const finenv_cashpenalty_panel *panel,
+                             const finenv_cashpenalty_state *state);
+int  finenv_cashpenalty_reset(finenv_cashpenalty *h, const uint8_t *mask, float *obs_out,
+                              void *stream);
+int  finenv_cashpenalty_step(finenv_cashpenalty *h, const float *actions, float *obs,
+                             float *reward, uint8_t *done, float *term_obs, int32_t auto_reset,
+                             void *stream);
 
 #ifdef __cplusplus
 }
