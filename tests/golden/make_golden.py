@@ -546,11 +546,109 @@ CASHPENALTY_SCENARIOS = {
 }
 
 
+# ----------------------------------------------------------------- stop-loss env
+def run_stoploss(name, *, seed, T, N, S, cols=("open", "close", "high", "low", "volume"),
+                 hmax=10, initial_amount=1e6, discrete_actions=False, shares_increment=1,
+                 stoploss_penalty=0.9, profit_loss_ratio=2, turbulence_threshold=None,
+                 patient=False, random_start=False, cash_penalty_proportion=0.1,
+                 buy_cost_pct=3e-3, sell_cost_pct=3e-3, act_scale=1.0, sigma=0.05):
+    """Unmodified reference StockTradingEnvStopLoss on a synthetic (volatile) OHLCV frame."""
+    import pandas as pd
+    rh.install()
+    import importlib
+    sys.modules.pop("finrl.meta.env_stock_trading.env_stocktrading_stoploss", None)
+    mod = importlib.import_module("finrl.meta.env_stock_trading.env_stocktrading_stoploss")
+    rng = np.random.default_rng(seed + 6000)
+    close = 50 * np.exp(np.cumsum(rng.normal(0, sigma, (T, N)), axis=0))
+    data = {"open": close * rng.uniform(0.99, 1.01, (T, N)), "close": close,
+            "high": close * 1.01, "low": close * 0.99,
+            "volume": rng.integers(1e5, 1e6, (T, N)).astype(np.float64)}
+    turb = np.abs(rng.normal(0, 30, T))
+    tics = [f"TIC{i:03d}" for i in range(N)]
+    frame = {"date": np.repeat([f"2020-{1 + t // 28:02d}-{1 + t % 28:02d}" for t in range(T)], N),
+             "tic": np.tile(tics, T)}
+    for c in set(cols) | {"close"}:
+        frame[c] = data[c].reshape(-1)
+    frame["turbulence"] = np.repeat(turb, N)
+    df = pd.DataFrame(frame)
+    buf = io.StringIO()
+    vec_keys = ("holdings", "avg_buy_price", "n_buys", "closing_diff_avg_buy",
+                "profit_sell_diff_avg_buy")
+    with contextlib.redirect_stdout(buf):
+        env = mod.StockTradingEnvStopLoss(
+            df=df, buy_cost_pct=buy_cost_pct, sell_cost_pct=sell_cost_pct, hmax=hmax,
+            discrete_actions=discrete_actions, shares_increment=shares_increment,
+            stoploss_penalty=stoploss_penalty, profit_loss_ratio=profit_loss_ratio,
+            turbulence_threshold=turbulence_threshold, print_verbosity=10 ** 9,
+            initial_amount=initial_amount, daily_information_cols=list(cols),
+            cache_indicator_data=True, cash_penalty_proportion=cash_penalty_proportion,
+            random_start=random_start, patient=patient)
+        act = (rng.uniform(-1, 1, (S, N)) * act_scale).astype(np.float32)
+        rec = {k: [] for k in ("obs", "reward", "done", "coh", "date_index", "sum_trades",
+                               "actual_num_trades") + vec_keys}
+        resets = dict(step=[-1], obs=[np.asarray(env.reset(), np.float64)],
+                      start=[env.starting_point])
+        for s in range(S):
+            obs, rew, done, info = env.step(act[s].copy())
+            rec["obs"].append(np.asarray(obs, np.float64))
+            rec["reward"].append(float(rew)); rec["done"].append(bool(done))
+            rec["coh"].append(float(env.state_memory[-1][0]))
+            rec["holdings"].append(np.asarray(env.state_memory[-1][1:N + 1], np.float64))
+            for k in vec_keys[1:]:
+                rec[k].append(np.asarray(getattr(env, k), np.float64).copy())
+            rec["date_index"].append(int(env.date_index))
+            rec["sum_trades"].append(float(env.sum_trades))
+            rec["actual_num_trades"].append(float(env.actual_num_trades))
+            if done:
+                resets["step"].append(s)
+                resets["obs"].append(np.asarray(env.reset(), np.float64))
+                resets["start"].append(env.starting_point)
+    reasons = sorted({r[2] for r in env.episode_history})
+    info = np.stack([data[c] for c in cols], axis=2)                             # [T, N, C]
+    out = dict(close=close, info=info, turb=turb, actions=act,
+               cfg_int=np.array([T, N, len(cols), S, int(discrete_actions), shares_increment,
+                                 int(turbulence_threshold is not None), int(patient)], np.int64),
+               cfg_float=np.array([hmax, buy_cost_pct, sell_cost_pct, initial_amount,
+                                   cash_penalty_proportion,
+                                   turbulence_threshold if turbulence_threshold is not None else 0.0,
+                                   stoploss_penalty, profit_loss_ratio]),
+               obs=np.stack(rec["obs"]), reward=np.asarray(rec["reward"]),
+               done=np.asarray(rec["done"]), coh=np.asarray(rec["coh"]),
+               date_index=np.asarray(rec["date_index"], np.int64),
+               sum_trades=np.asarray(rec["sum_trades"]),
+               actual_num_trades=np.asarray(rec["actual_num_trades"]),
+               reset_step=np.asarray(resets["step"], np.int64), reset_obs=np.stack(resets["obs"]),
+               reset_start=np.asarray(resets["start"], np.int64),
+               meta=np.array(["variant=O-raw", f"seed={seed}", f"numpy={np.__version__}",
+                              "reasons=" + ",".join(reasons),
+                              "source=finrl/meta/env_stock_trading/"
+                              "env_stocktrading_stoploss.py (unmodified)"]))
+    for k in vec_keys:
+        out[k] = np.stack(rec[k])
+    path = os.path.join(HERE, f"stoploss_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB) steps={S} "
+          f"dones={int(np.sum(rec['done']))} final_coh={rec['coh'][-1]:.2f} reasons={reasons}")
+    return out
+
+
+STOPLOSS_SCENARIOS = {
+    "continuous": dict(seed=71, T=24, N=30, S=60, hmax=3_000, turbulence_threshold=55.0),
+    "invested": dict(seed=72, T=30, N=5, S=70, hmax=150_000, sigma=0.06),
+    "patient": dict(seed=73, T=20, N=5, S=45, hmax=400_000, patient=True, act_scale=1.5),
+    "discrete": dict(seed=74, T=20, N=8, S=45, hmax=10_000, discrete_actions=True,
+                     shares_increment=5, cols=("close", "volume"), turbulence_threshold=40.0),
+    "randstart": dict(seed=75, T=30, N=3, S=60, hmax=30_000, random_start=True,
+                      stoploss_penalty=0.95, profit_loss_ratio=3),
+}
+
+
 def main(argv):
     names = argv or (list(STOCK_SCENARIOS) + ["portfolio:" + k for k in PORTFOLIO_SCENARIOS]
                      + ["crypto:" + k for k in CRYPTO_SCENARIOS]
                      + ["stocknp:" + k for k in STOCKNP_SCENARIOS]
-                     + ["cashpenalty:" + k for k in CASHPENALTY_SCENARIOS])
+                     + ["cashpenalty:" + k for k in CASHPENALTY_SCENARIOS]
+                     + ["stoploss:" + k for k in STOPLOSS_SCENARIOS])
     for n in names:
         if n in STOCK_SCENARIOS:
             run_stock(n, **STOCK_SCENARIOS[n])
@@ -558,6 +656,8 @@ def main(argv):
             run_portfolio(n[10:], **PORTFOLIO_SCENARIOS[n[10:]])
         elif n.startswith("cashpenalty:") and n[12:] in CASHPENALTY_SCENARIOS:
             run_cashpenalty(n[12:], **CASHPENALTY_SCENARIOS[n[12:]])
+        elif n.startswith("stoploss:") and n[9:] in STOPLOSS_SCENARIOS:
+            run_stoploss(n[9:], **STOPLOSS_SCENARIOS[n[9:]])
         elif n.startswith("stocknp:") and n[8:] in STOCKNP_SCENARIOS:
             run_stocknp(n[8:], **STOCKNP_SCENARIOS[n[8:]])
         elif n.startswith("crypto:") and n[7:] in CRYPTO_SCENARIOS:
