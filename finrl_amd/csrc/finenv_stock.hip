@@ -255,6 +255,9 @@ int finenv_struct_size(int which)
     case 12: return (int)sizeof(finenv_cashpenalty_config);
     case 13: return (int)sizeof(finenv_cashpenalty_panel);
     case 14: return (int)sizeof(finenv_cashpenalty_state);
+    case 15: return (int)sizeof(finenv_stoploss_config);
+    case 16: return (int)sizeof(finenv_stoploss_panel);
+    case 17: return (int)sizeof(finenv_stoploss_state);
     default: return FINENV_ERR_INVALID;
     }
 }

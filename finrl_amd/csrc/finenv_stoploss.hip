@@ -1,0 +1,447 @@
+// finenv_stoploss.hip -- MI355X (gfx950) kernel + C ABI for the batched stop-loss env
+// (finrl/meta/env_stock_trading/env_stocktrading_stoploss.py: step :292-442,
+// get_reward :255-290, reset :134-165).
+//
+// lane = env, one wave per 64 envs.  Per-asset books (holdings, previous holdings, the two
+// price-vs-average-buy differences, buy counts, average buy price) live in HBM as [N][E] f64
+// rows, so every per-asset access of a wave is one coalesced 512-B row segment.  Three short
+// fp64 passes over the assets: (1) previous-state reward terms, (2) transactions + stop-loss
+// override + cash test inputs, (3) book update.  Sums run in asset order, like the oracle.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "finenv.h"
+#include "finenv_dev.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kMaxN = FINENV_STOPLOSS_MAX_ASSETS;
+constexpr int kRow = kMaxN + 1;
+constexpr int kWaves = 2;
+constexpr int kLdsPerWave = kWave * kRow + kMaxN * kWave * 2;   // rows + f64 transactions [i][lane]
+
+struct SlParams {
+    finenv_stoploss_config cfg;
+    finenv_stoploss_panel panel;
+    finenv_stoploss_state st;
+    const float *actions;
+    float *obs;
+    float *reward;
+    uint8_t *done;
+    float *term_obs;
+    const uint8_t *mask;
+    int32_t auto_reset;
+    int32_t D;
+    uint32_t magicN;
+};
+
+#define LF(fld) (*at(p.st.f64, (unsigned)(fld) * (unsigned)E + (unsigned)e))
+#define LI(fld) (*at(p.st.i32, (unsigned)(fld) * (unsigned)E + (unsigned)e))
+#define LV(book, i) LF(FINENV_STOPLOSS_F64_FIELDS + (book) * N + (i))
+
+__device__ __forceinline__ double sl_floordiv(double a, double d)       // exact floor(a/d), d > 0
+{
+    double x = __builtin_amdgcn_rcp(d);
+    x = fma(fma(-d, x, 1.0), x, x);
+    double q = floor(a * x);
+    double r = fma(-q, d, a);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        q += (r < 0.0) ? -1.0 : ((r >= d) ? 1.0 : 0.0);
+        r = fma(-q, d, a);
+    }
+    return q;
+}
+
+// get_reward(), :255-290, from its four sums
+__device__ __forceinline__ double sl_reward(const finenv_stoploss_config &c, int step,
+                                            double total, double cash, double slp_sum,
+                                            double lpp_sum, double add)
+{
+    if (step == 0) return 0.0;
+    const double cash_penalty = fmax(0.0, total * c.cash_penalty_proportion - cash);   // :270
+    const double slp = step > 1 ? -slp_sum : 0.0;                                       // :271-277
+    const double lpp = -lpp_sum;                                                        // :278-280
+    const double total_penalty = cash_penalty + slp + lpp;                              // :281
+    double r = ((total - total_penalty + add) / c.initial_amount) - 1;                  // :285-287
+    r /= (double)step;                                                                  // :288
+    return r;
+}
+
+// rows[el*kRow + 0] = f32 cash, rows[el*kRow + 1 + i] = f32 holdings_i; columns > N: info row
+__device__ __forceinline__ void sl_write_rows(float *__restrict__ dst, const SlParams &p, int e0,
+                                              int nenv_w, int row_day,
+                                              unsigned long long lane_mask, const float *rows,
+                                              int lane)
+{
+    if (lane_mask == 0ull) return;
+    const int N = p.cfg.n_assets, D = p.D, W = D - 1 - N;
+    const int first = __builtin_ctzll(lane_mask);
+    const int d0 = __builtin_amdgcn_readlane(row_day, first);
+    const bool mine = (lane_mask >> lane) & 1ull;
+    const bool uniform = __all(!mine || row_day == d0);
+    float *const base = dst + (size_t)e0 * D;
+    const int nchunk = (D + kWave - 1) / kWave;
+    for (int k = 0; k < nchunk; ++k) {
+        const int col = k * kWave + lane;
+        const bool in = col < D;
+        const bool head = col <= N;
+        const bool any_head = __any(in && head);
+        float t = 0.0f;
+        if (uniform && in && !head) t = *at(p.panel.info, (unsigned)(d0 * W + col - 1 - N));
+        for (int el = 0; el < nenv_w; ++el) {
+            if (!((lane_mask >> el) & 1ull)) continue;
+            float v = t;
+            if (!uniform) {
+                const int de = __builtin_amdgcn_readlane(row_day, el);
+                if (in && !head) v = *at(p.panel.info, (unsigned)(de * W + col - 1 - N));
+            }
+            if (any_head) {
+                const float hv = rows[el * kRow + (head ? col : 0)];
+                v = head ? hv : v;
+            }
+            if (in) *at(base, (unsigned)(el * D + col)) = v;
+        }
+    }
+}
+
+template <bool RESET_ONLY>
+__global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams p)
+{
+    __shared__ __attribute__((aligned(16))) float lds_all[kWaves * kLdsPerWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib = threadIdx.x >> 6;
+    float *rows = lds_all + wib * kLdsPerWave;
+    double *trl = reinterpret_cast<double *>(rows + kWave * kRow + ((kWave * kRow) & 1));
+    const int E = p.cfg.n_envs, N = p.cfg.n_assets;
+    const int e0 = (blockIdx.x * kWaves + wib) * kWave;
+    if (e0 >= E) return;
+    const int nenv_w = min(kWave, E - e0);
+    const bool valid = lane < nenv_w;
+    const int e = valid ? e0 + lane : e0;
+    float *row = rows + lane * kRow;
+    const finenv_stoploss_config &c = p.cfg;
+
+    if (RESET_ONLY) {                                                          // :134-165
+        const bool sel = valid && (p.mask == nullptr || p.mask[e] != 0);
+        const int start = LI(FINENV_LI_NEXT_START);
+        if (sel) {
+            LI(FINENV_LI_START) = start;
+            LI(FINENV_LI_DATE_INDEX) = start;
+            LI(FINENV_LI_EPISODE) += 1;
+            LF(FINENV_LF_TURBULENCE) = 0.0;
+            LF(FINENV_LF_SUM_TRADES) = 0.0;
+            LF(FINENV_LF_ACTUAL_NUM_TRADES) = 0.0;
+            LF(FINENV_LF_COH) = c.initial_amount;
+            for (int i = 0; i < FINENV_STOPLOSS_BOOKS * N; ++i) LV(0, i) = 0.0;
+        }
+        if (p.obs == nullptr) return;
+        row[0] = (float)c.initial_amount;
+        for (int i = 0; i < N; ++i) row[1 + i] = 0.0f;
+        wave_sync();
+        sl_write_rows(p.obs, p, e0, nenv_w, start, __ballot(sel), rows, lane);
+        return;
+    }
+
+    // ---- action tile -> LDS rows --------------------------------------------------------------
+    {
+        const float *__restrict__ src = p.actions + (size_t)e0 * N;
+        const int total = nenv_w * N;
+        for (int f = lane; f < total; f += kWave) {
+            const int el = (N == 1) ? f : (int)__umulhi((unsigned)f, p.magicN);
+            rows[el * kRow + (f - el * N)] = *at(src, (unsigned)f);
+        }
+    }
+    int di = LI(FINENV_LI_DATE_INDEX);
+    const int start = LI(FINENV_LI_START);
+    double coh = LF(FINENV_LF_COH);
+    double turb = c.use_turbulence ? LF(FINENV_LF_TURBULENCE) : 0.0;
+    double sum_trades = LF(FINENV_LF_SUM_TRADES);
+    double logged_total = LF(FINENV_LF_LOGGED_TOTAL), logged_cash = LF(FINENV_LF_LOGGED_CASH);
+    double actual_num_trades = LF(FINENV_LF_ACTUAL_NUM_TRADES);
+    const int step = di - start;                                                 // current_step
+    const bool at_end = di == c.n_days - 1;                                      // :302
+    const unsigned cb = (unsigned)(di * N);
+    wave_sync();
+
+    // ---- pass 1: reward terms of the state as the previous step left it (:313 / :304) ---------
+    double slp_sum = 0.0, lpp_sum = 0.0, add = 0.0;
+    for (int i = 0; i < N; ++i) {
+        sum_trades += fabs((double)row[i]);                                      // :294
+        const double h = LV(FINENV_LV_HOLDINGS, i);
+        const double ps = LV(FINENV_LV_PROFIT_SELL_DIFF_AVG_BUY, i);
+        slp_sum += LV(FINENV_LV_PREV_HOLDINGS, i) *
+                   fmin(LV(FINENV_LV_CLOSING_DIFF_AVG_BUY, i), 0.0);             // :262,:273-275
+        lpp_sum += h * fmin(ps, 0.0);                                            // :263-265,:278-280
+        add += h * fmax(ps, 0.0);                                                // :266-268,:283
+    }
+    double reward = sl_reward(c, step, logged_total, logged_cash, slp_sum, lpp_sum, add);
+    bool done = at_end;
+
+    // ---- pass 2: transactions (:320-357), proceeds / spend (:363-370) --------------------------
+    const float hmaxf = (float)c.hmax;
+    const bool turbulent = c.use_turbulence && turb >= c.turbulence_threshold;
+    const bool stop_armed = coh >= c.stoploss_penalty * c.initial_amount;        // :353
+    double asset_value = 0.0, proceeds = 0.0, spend = 0.0, slp_new = 0.0;
+    bool keep_buys = true;
+    double coh_new = coh;
+    if (!at_end) {
+        for (int i = 0; i < N; ++i) {
+            const double h = LV(FINENV_LV_HOLDINGS, i);
+            const double cl = *at(p.panel.close, cb + (unsigned)i);
+            const double abp = LV(FINENV_LV_AVG_BUY_PRICE, i);
+            asset_value += h * cl;                                               // :311
+            const float a32 = row[i] * hmaxf;                                    // :321 (float32)
+            double a = cl > 0.0 ? (double)a32 : 0.0;                             // :326
+            a = turbulent ? -(h * cl) : a;                                       // :327-331
+            double tr;
+            if (c.discrete_actions) {                                            // :333-343
+                long long q = cl > 0.0 ? (long long)sl_floordiv(a, cl) : 0ll;
+                const long long inc = c.shares_increment;
+                const long long num = q >= 0 ? q : q + inc;
+                long long fq = num / inc;
+                if ((num % inc != 0) && ((num < 0) != (inc < 0))) fq -= 1;
+                tr = (double)(fq * inc);
+            } else {
+                tr = cl > 0.0 ? a / cl : 0.0;                                    // :345
+            }
+            tr = fmax(tr, -h);                                                   // :348
+            const double cd = cl - (c.stoploss_penalty * abp);                   // :350-352
+            if (valid) LV(FINENV_LV_CLOSING_DIFF_AVG_BUY, i) = cd;
+            slp_new += LV(FINENV_LV_PREV_HOLDINGS, i) * fmin(cd, 0.0);
+            tr = (stop_armed && cd < 0.0) ? -h : tr;                             // :353-357
+            trl[i * kWave + lane] = tr;
+            proceeds += (tr < 0.0 ? -tr : 0.0) * cl;                             // :363-364
+            spend += (tr > 0.0 ? tr : 0.0) * cl;                                 // :368-369
+        }
+        logged_cash = coh;                                                       // :315-317
+        logged_total = coh + asset_value;
+        double costs = proceeds * c.sell_cost_pct;                               // :365
+        const double coh1 = coh + proceeds;                                      // :366
+        costs += spend * c.buy_cost_pct;                                         // :370
+        if (spend + costs > coh1) {                                              // :372
+            if (c.patient) {                                                     // :373-378
+                keep_buys = false;
+                spend = 0.0;
+                costs = 0.0;
+            } else {                                                             // :379-383
+                done = true;
+                reward = sl_reward(c, step, logged_total, logged_cash, slp_new, lpp_sum, add);
+            }
+        }
+        coh_new = coh1 - spend - costs;                                          // :414
+    }
+
+    // ---- pass 3: book update (:388-428) --------------------------------------------------------
+    const bool advance = !done;
+    if (advance) {
+        coh = coh_new;
+        double ntr = 0.0;
+        for (int i = 0; i < N; ++i) {
+            const double tr0 = trl[i * kWave + lane];
+            const double cl = *at(p.panel.close, cb + (unsigned)i);
+            const double h = LV(FINENV_LV_HOLDINGS, i);
+            double abp = LV(FINENV_LV_AVG_BUY_PRICE, i);
+            double nb = LV(FINENV_LV_N_BUYS, i);
+            const bool sold = tr0 < 0.0;                                         // sells > 0
+            const bool bought = tr0 > 0.0;                                       // buys > 0 (:418)
+            const double tr = (bought && !keep_buys) ? 0.0 : tr0;                // :376
+            const double scp = sold ? cl : 0.0;                                  // :388-390
+            const bool profit = scp - abp > 0.0;                                 // :391-393
+            const double ps = profit ? cl - (c.min_profit_penalty * abp) : 0.0;  // :395-399
+            ntr += tr != 0.0 ? 1.0 : 0.0;                                        // :411
+            const double hu = h + tr;                                            // :415
+            nb += bought ? 1.0 : 0.0;                                            // :419
+            const double abp_new = abp + ((cl - abp) / nb);                      // :420-424
+            abp = bought ? abp_new : abp;
+            const bool held = hu > 0.0;                                          // :427-428
+            nb = held ? nb : 0.0;
+            abp = held ? abp : 0.0;
+            if (valid) {
+                LV(FINENV_LV_PROFIT_SELL_DIFF_AVG_BUY, i) = ps;
+                LV(FINENV_LV_PREV_HOLDINGS, i) = h;
+                LV(FINENV_LV_HOLDINGS, i) = hu;
+                LV(FINENV_LV_N_BUYS, i) = nb;
+                LV(FINENV_LV_AVG_BUY_PRICE, i) = abp;
+            }
+            row[1 + i] = (float)hu;
+        }
+        actual_num_trades = ntr;
+        di += 1;                                                                 // :430
+        if (c.use_turbulence) turb = *at(p.panel.turb, (unsigned)di);            // :431-434
+    } else {
+        for (int i = 0; i < N; ++i) row[1 + i] = (float)LV(FINENV_LV_HOLDINGS, i);
+    }
+    row[0] = (float)coh;
+    if (valid) {
+        *at(p.reward, (unsigned)e) = (float)reward;
+        *at(p.done, (unsigned)e) = done ? 1 : 0;
+        LF(FINENV_LF_SUM_TRADES) = sum_trades;
+        LF(FINENV_LF_LOGGED_TOTAL) = logged_total;
+        LF(FINENV_LF_LOGGED_CASH) = logged_cash;
+        LF(FINENV_LF_ACTUAL_NUM_TRADES) = actual_num_trades;
+    }
+    wave_sync();
+    const unsigned long long valid_mask = __ballot(valid);
+    const unsigned long long done_mask = __ballot(done && valid);
+    int row_day = di;
+    if (done_mask != 0ull) {
+        if (p.term_obs != nullptr)
+            sl_write_rows(p.term_obs, p, e0, nenv_w, di, done_mask, rows, lane);
+        if (p.auto_reset) {                                                      // reset()
+            wave_sync();
+            if (done) {
+                const int ns = LI(FINENV_LI_NEXT_START);
+                di = ns;
+                row_day = ns;
+                coh = c.initial_amount;
+                turb = 0.0;
+                row[0] = (float)coh;
+                for (int i = 0; i < N; ++i) row[1 + i] = 0.0f;
+                if (valid) {
+                    for (int i = 0; i < FINENV_STOPLOSS_BOOKS * N; ++i) LV(0, i) = 0.0;
+                    LI(FINENV_LI_START) = ns;
+                    LI(FINENV_LI_EPISODE) += 1;
+                    LF(FINENV_LF_SUM_TRADES) = 0.0;
+                    LF(FINENV_LF_ACTUAL_NUM_TRADES) = 0.0;
+                }
+            }
+            wave_sync();
+        }
+    }
+    sl_write_rows(p.obs, p, e0, nenv_w, row_day, valid_mask, rows, lane);
+    if (valid) {
+        LF(FINENV_LF_COH) = coh;
+        LI(FINENV_LI_DATE_INDEX) = di;
+        if (c.use_turbulence) LF(FINENV_LF_TURBULENCE) = turb;
+    }
+}
+
+}  // namespace
+
+struct finenv_stoploss {
+    finenv_stoploss_config cfg;
+    finenv_stoploss_panel panel;
+    finenv_stoploss_state st;
+    int bound;
+    int D;
+    uint32_t magicN;
+    char err[256];
+};
+
+namespace {
+int sl_fail(finenv_stoploss *h, int code, const char *msg)
+{
+    if (h) snprintf(h->err, sizeof(h->err), "%s", msg);
+    return code;
+}
+int sl_check(finenv_stoploss *h, const char *what)
+{
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(h->err, sizeof(h->err), "%s: %s", what, hipGetErrorString(e));
+        return FINENV_ERR_HIP;
+    }
+    return FINENV_OK;
+}
+SlParams sl_params(const finenv_stoploss *h)
+{
+    SlParams p;
+    memset(&p, 0, sizeof(p));
+    p.cfg = h->cfg;
+    p.panel = h->panel;
+    p.st = h->st;
+    p.D = h->D;
+    p.magicN = h->magicN;
+    return p;
+}
+dim3 sl_grid(int E)
+{
+    const int waves = (E + kWave - 1) / kWave;
+    return dim3((unsigned)((waves + kWaves - 1) / kWaves));
+}
+}  // namespace
+
+extern "C" {
+
+int finenv_stoploss_create(const finenv_stoploss_config *cfg, finenv_stoploss **out)
+{
+    if (!cfg || !out) return FINENV_ERR_INVALID;
+    *out = nullptr;
+    if (cfg->n_envs < 1 || cfg->n_assets < 1 || cfg->n_assets > FINENV_STOPLOSS_MAX_ASSETS ||
+        cfg->n_cols < 0 || cfg->n_days < 1 || cfg->shares_increment < 1 || !(cfg->hmax >= 0) ||
+        !(cfg->initial_amount > 0))
+        return FINENV_ERR_INVALID;
+    const long long E = cfg->n_envs, N = cfg->n_assets, T = cfg->n_days;
+    const long long D = 1 + N + N * cfg->n_cols, lim = (1ll << 32) - 1;
+    if ((FINENV_STOPLOSS_F64_FIELDS + FINENV_STOPLOSS_BOOKS * N) * E * 8 > lim ||
+        T * N * cfg->n_cols * 4 > lim || T * N * 8 > lim || 64 * D * 4 > lim || E * N * 4 > lim)
+        return FINENV_ERR_INVALID;
+    finenv_stoploss *h = new (std::nothrow) finenv_stoploss;
+    if (!h) return FINENV_ERR_NOMEM;
+    memset(h, 0, sizeof(*h));
+    h->cfg = *cfg;
+    h->D = (int)D;
+    h->magicN = N >= 2 ? (uint32_t)(((1ull << 32) + N - 1) / (unsigned long long)N) : 0u;
+    *out = h;
+    return FINENV_OK;
+}
+
+void finenv_stoploss_destroy(finenv_stoploss *h) { delete h; }
+const char *finenv_stoploss_last_error(const finenv_stoploss *h)
+{
+    return h ? h->err : "null handle";
+}
+int finenv_stoploss_obs_dim(const finenv_stoploss *h) { return h ? h->D : FINENV_ERR_INVALID; }
+
+int finenv_stoploss_bind(finenv_stoploss *h, const finenv_stoploss_panel *panel,
+                         const finenv_stoploss_state *st)
+{
+    if (!h || !panel || !st) return FINENV_ERR_INVALID;
+    if (!panel->close || (!panel->info && h->cfg.n_cols > 0) ||
+        (!panel->turb && h->cfg.use_turbulence) || !st->f64 || !st->i32)
+        return sl_fail(h, FINENV_ERR_INVALID, "bind: null pointer");
+    h->panel = *panel;
+    h->st = *st;
+    h->bound = 1;
+    return FINENV_OK;
+}
+
+int finenv_stoploss_reset(finenv_stoploss *h, const uint8_t *mask, float *obs_out, void *stream)
+{
+    if (!h) return FINENV_ERR_INVALID;
+    if (!h->bound) return sl_fail(h, FINENV_ERR_UNBOUND, "reset: bind first");
+    SlParams p = sl_params(h);
+    p.mask = mask;
+    p.obs = obs_out;
+    hipLaunchKernelGGL((stoploss_kernel<true>), sl_grid(h->cfg.n_envs), dim3(kWave * kWaves), 0,
+                       (hipStream_t)stream, p);
+    return sl_check(h, "stoploss_reset");
+}
+
+int finenv_stoploss_step(finenv_stoploss *h, const float *actions, float *obs, float *reward,
+                         uint8_t *done, float *term_obs, int32_t auto_reset, void *stream)
+{
+    if (!h) return FINENV_ERR_INVALID;
+    if (!h->bound) return sl_fail(h, FINENV_ERR_UNBOUND, "step: bind first");
+    if (!actions || !obs || !reward || !done)
+        return sl_fail(h, FINENV_ERR_INVALID, "step: null actions/obs/reward/done");
+    SlParams p = sl_params(h);
+    p.actions = actions;
+    p.obs = obs;
+    p.reward = reward;
+    p.done = done;
+    p.term_obs = term_obs;
+    p.auto_reset = auto_reset;
+    hipLaunchKernelGGL((stoploss_kernel<false>), sl_grid(h->cfg.n_envs), dim3(kWave * kWaves), 0,
+                       (hipStream_t)stream, p);
+    return sl_check(h, "stoploss_step");
+}
+
+}  // extern "C"

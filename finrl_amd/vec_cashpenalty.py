@@ -44,11 +44,24 @@ class CashPenaltyPanel:
 class VecCashPenaltyEnv:
     env_name = "StockTradingEnvCashpenalty-MI355X"
     if_discrete = False
+    _kind = "cashpenalty"                      # finenv_<kind>_* entry points
+    _cfg_cls, _panel_cls, _state_cls = nat.CashPenaltyConfig, nat.CashPenaltyPanelPtrs, \
+        nat.CashPenaltyStatePtrs
+    _f64_fields, _i32_fields = nat.CASHPENALTY_F64_FIELDS, nat.CASHPENALTY_I32_FIELDS
+    _books = ("holdings",)                     # [N][E] f64 blocks after the scalar rows
+
+    def _extra_cfg(self, **kw):
+        if kw:
+            raise TypeError(f"unexpected arguments {sorted(kw)}")
+        return ()
+
+    def _fn(self, name):
+        return getattr(nat.lib(), f"finenv_{self._kind}_{name}")
 
     def __init__(self, panel: CashPenaltyPanel, num_envs, *, buy_cost_pct=3e-3, sell_cost_pct=3e-3,
                  hmax=10, discrete_actions=False, shares_increment=1, turbulence_threshold=None,
                  initial_amount=1e6, cash_penalty_proportion=0.1, random_start=True, patient=False,
-                 auto_reset=True, device="cuda", seed=0):
+                 auto_reset=True, device="cuda", seed=0, **extra):
         import torch
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -65,30 +78,32 @@ class VecCashPenaltyEnv:
         self._gen = torch.Generator(device=self.device)
         self._gen.manual_seed(seed)
         L = nat.lib()
-        self._cfg = nat.CashPenaltyConfig(
+        self._cfg = self._cfg_cls(
             E, N, Cc, T, int(discrete_actions), int(shares_increment),
             int(turbulence_threshold is not None), int(patient), float(hmax), float(buy_cost_pct),
             float(sell_cost_pct), float(initial_amount), float(cash_penalty_proportion),
-            float(turbulence_threshold if turbulence_threshold is not None else 0.0))
+            float(turbulence_threshold if turbulence_threshold is not None else 0.0),
+            *self._extra_cfg(**extra))
         self._h = C.c_void_p()
-        nat.check(L.finenv_cashpenalty_create(C.byref(self._cfg), C.byref(self._h)), None,
-                  "finenv_cashpenalty_create")
+        nat.check(self._fn("create")(C.byref(self._cfg), C.byref(self._h)), None,
+                  f"finenv_{self._kind}_create")
         dev = self.device
         self._close = torch.from_numpy(panel.close).to(dev)
         self._info = torch.from_numpy(panel.info.reshape(T, N * Cc).astype(np.float32)).to(dev)
         self._turb = torch.from_numpy(panel.turb).to(dev)
-        nf, ni = len(nat.CASHPENALTY_F64_FIELDS), len(nat.CASHPENALTY_I32_FIELDS)
-        self._f64 = torch.zeros(nf + N, E, dtype=torch.float64, device=dev)
+        nf, ni = len(self._f64_fields), len(self._i32_fields)
+        self._f64 = torch.zeros(nf + len(self._books) * N, E, dtype=torch.float64, device=dev)
         self._i32 = torch.zeros(ni, E, dtype=torch.int32, device=dev)
-        self.state = {k: self._f64[j] for j, k in enumerate(nat.CASHPENALTY_F64_FIELDS)}
-        self.state.update({k: self._i32[j] for j, k in enumerate(nat.CASHPENALTY_I32_FIELDS)})
-        self.state["holdings"] = self._f64[nf:nf + N]
+        self.state = {k: self._f64[j] for j, k in enumerate(self._f64_fields)}
+        self.state.update({k: self._i32[j] for j, k in enumerate(self._i32_fields)})
+        for b, k in enumerate(self._books):
+            self.state[k] = self._f64[nf + b * N:nf + (b + 1) * N]
         self.state["episode"].fill_(-1)                                         # :98
-        pp = nat.CashPenaltyPanelPtrs(self._close.data_ptr(), self._info.data_ptr(),
-                                      self._turb.data_ptr())
-        sp = nat.CashPenaltyStatePtrs(self._f64.data_ptr(), self._i32.data_ptr())
-        nat.check(L.finenv_cashpenalty_bind(self._h, C.byref(pp), C.byref(sp)), self._h, "bind",
-                  "cashpenalty")
+        pp = self._panel_cls(self._close.data_ptr(), self._info.data_ptr(),
+                             self._turb.data_ptr())
+        sp = self._state_cls(self._f64.data_ptr(), self._i32.data_ptr())
+        nat.check(self._fn("bind")(self._h, C.byref(pp), C.byref(sp)), self._h, "bind",
+                  self._kind)
         self.obs = torch.zeros(E, panel.D, dtype=torch.float32, device=dev)
         self.reward = torch.zeros(E, dtype=torch.float32, device=dev)
         self.done = torch.zeros(E, dtype=torch.uint8, device=dev)
@@ -101,7 +116,7 @@ class VecCashPenaltyEnv:
     def __del__(self):
         try:
             if getattr(self, "_h", None):
-                nat.lib().finenv_cashpenalty_destroy(self._h)
+                self._fn("destroy")(self._h)
                 self._h = None
         except Exception:
             pass
@@ -133,9 +148,9 @@ class VecCashPenaltyEnv:
         if mask is not None:
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
             mptr = C.c_void_p(mask.data_ptr())
-        nat.check(nat.lib().finenv_cashpenalty_reset(
+        nat.check(self._fn("reset")(
             self._h, mptr, C.c_void_p(self.obs.data_ptr()), self._stream()), self._h, "reset",
-            "cashpenalty")
+            self._kind)
         return self.obs
 
     def step(self, actions, out=None):
@@ -146,14 +161,31 @@ class VecCashPenaltyEnv:
         if self.random_start and self.auto_reset:
             self._draw_starts()          # fresh starting points for envs that end this step
         obs, rew, done = out if out is not None else (self.obs, self.reward, self.done)
-        nat.check(nat.lib().finenv_cashpenalty_step(
+        nat.check(self._fn("step")(
             self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(obs.data_ptr()),
             C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()),
             C.c_void_p(self.term_obs.data_ptr()) if self.term_obs is not None else None,
-            int(self.auto_reset), self._stream()), self._h, "step", "cashpenalty")
+            int(self.auto_reset), self._stream()), self._h, "step", self._kind)
         return obs, rew, done, None
 
     def state_numpy(self):
         out = {k: v.detach().cpu().numpy() for k, v in self.state.items()}
-        out["holdings"] = np.ascontiguousarray(out["holdings"].T)
+        for k in self._books:
+            out[k] = np.ascontiguousarray(out[k].T)
         return out
+
+
+class VecStopLossEnv(VecCashPenaltyEnv):
+    """Device-resident batch of the reference's StockTradingEnvStopLoss
+    (finrl/meta/env_stock_trading/env_stocktrading_stoploss.py:19-459); extra kwargs
+    stoploss_penalty (:73) and profit_loss_ratio (:74)."""
+    env_name = "StockTradingEnvStopLoss-MI355X"
+    _kind = "stoploss"
+    _cfg_cls, _panel_cls, _state_cls = nat.StopLossConfig, nat.StopLossPanelPtrs, \
+        nat.StopLossStatePtrs
+    _f64_fields, _i32_fields = nat.STOPLOSS_F64_FIELDS, nat.STOPLOSS_I32_FIELDS
+    _books = nat.STOPLOSS_BOOKS
+
+    def _extra_cfg(self, stoploss_penalty=0.9, profit_loss_ratio=2):
+        min_profit_penalty = 1 + profit_loss_ratio * (1 - stoploss_penalty)      # :101
+        return float(stoploss_penalty), float(min_profit_penalty)

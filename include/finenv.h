@@ -127,7 +127,7 @@ typedef struct finenv_stock finenv_stock;   /* opaque host-side handle */
 int         finenv_abi_version(void);
 /* sizeof() of the ABI structs as the library was compiled (0 = finenv_stock_config,
  * 1 = finenv_stock_panel, 2 = finenv_stock_state, 3..5 = the finenv_portfolio_* trio, 6..8 = the finenv_crypto_* trio, 9..11 = the finenv_stocknp_* trio,
- * 12..14 = the finenv_cashpenalty_* trio): lets a foreign-language binding verify its
+ * 12..14 = the finenv_cashpenalty_* trio, 15..17 = the finenv_stoploss_* trio): lets a foreign-language binding verify its
  * struct declarations at load time instead of corrupting memory. */
 int         finenv_struct_size(int which);
 const char *finenv_strerror(int code);
@@ -408,6 +408,66 @@ int  finenv_cashpenalty_reset(finenv_cashpenalty *h, const uint8_t *mask, float 
 int  finenv_cashpenalty_step(finenv_cashpenalty *h, const float *actions, float *obs,
                              float *reward, uint8_t *done, float *term_obs, int32_t auto_reset,
                              void *stream);
+
+/* =====================================================================================
+ * StockTradingEnvStopLoss
+ * (finrl/meta/env_stock_trading/env_stocktrading_stoploss.py:19-459): the cash-penalty env
+ * plus an average-buy-price book per asset: positions are force-sold when
+ * close < stoploss_penalty * avg_buy_price (and cash >= stoploss_penalty * initial, :353-357);
+ * the reward adds a stop-loss penalty, a low-profit penalty and a profit bonus (:255-290).
+ * Quirks kept (see oracle/stoploss_oracle.c): per-step reward uses the PREVIOUS step's
+ * logged totals (:313 precedes :315-318); the turbulence sell-off goes through
+ * (h*close)/close (:330,:345); patient mode still books the cancelled buys (:376 vs :418).
+ *   actions [E][N] f32;  obs [E][D] f32, D = 1 + N + N*C  (same layout as the cash-penalty env)
+ * ===================================================================================== */
+#define FINENV_STOPLOSS_MAX_ASSETS 32
+
+typedef struct finenv_stoploss_config {
+    int32_t n_envs, n_assets, n_cols, n_days;
+    int32_t discrete_actions;     /* :71, :333-343                                        */
+    int32_t shares_increment;     /* :72                                                  */
+    int32_t use_turbulence;       /* turbulence_threshold is not None, :327-331           */
+    int32_t patient;              /* :373-378                                             */
+    double  hmax;                 /* :70 (scalar)                                         */
+    double  buy_cost_pct, sell_cost_pct, initial_amount, cash_penalty_proportion,
+            turbulence_threshold;
+    double  stoploss_penalty;     /* :73                                                  */
+    double  min_profit_penalty;   /* 1 + profit_loss_ratio * (1 - stoploss_penalty), :101 */
+} finenv_stoploss_config;
+
+typedef struct finenv_stoploss_panel {
+    const double *close;          /* [T][N] f64                                           */
+    const float  *info;           /* [T][N*C] f32 date vectors, ticker-major (:167-180)   */
+    const double *turb;           /* [T] f64 (may be NULL when use_turbulence == 0)       */
+} finenv_stoploss_panel;
+
+enum { FINENV_LF_COH = 0, FINENV_LF_TURBULENCE, FINENV_LF_SUM_TRADES, FINENV_LF_LOGGED_TOTAL,
+       FINENV_LF_LOGGED_CASH, FINENV_LF_ACTUAL_NUM_TRADES, FINENV_STOPLOSS_F64_FIELDS };
+/* after the scalar rows, six [N][E] f64 books in this order */
+enum { FINENV_LV_HOLDINGS = 0, FINENV_LV_PREV_HOLDINGS, FINENV_LV_CLOSING_DIFF_AVG_BUY,
+       FINENV_LV_PROFIT_SELL_DIFF_AVG_BUY, FINENV_LV_N_BUYS, FINENV_LV_AVG_BUY_PRICE,
+       FINENV_STOPLOSS_BOOKS };
+enum { FINENV_LI_DATE_INDEX = 0, FINENV_LI_START, FINENV_LI_EPISODE, FINENV_LI_NEXT_START,
+       FINENV_STOPLOSS_I32_FIELDS };
+
+typedef struct finenv_stoploss_state {
+    double  *f64;                 /* [FINENV_STOPLOSS_F64_FIELDS + FINENV_STOPLOSS_BOOKS*N][E] */
+    int32_t *i32;                 /* [FINENV_STOPLOSS_I32_FIELDS][E]                           */
+} finenv_stoploss_state;
+
+typedef struct finenv_stoploss finenv_stoploss;
+
+int  finenv_stoploss_create(const finenv_stoploss_config *cfg, finenv_stoploss **out);
+void finenv_stoploss_destroy(finenv_stoploss *h);
+const char *finenv_stoploss_last_error(const finenv_stoploss *h);
+int  finenv_stoploss_obs_dim(const finenv_stoploss *h);
+int  finenv_stoploss_bind(finenv_stoploss *h, const finenv_stoploss_panel *panel,
+                          const finenv_stoploss_state *state);
+/* reset(), :134-165 (mask NULL = all envs; starting points from FINENV_LI_NEXT_START) */
+int  finenv_stoploss_reset(finenv_stoploss *h, const uint8_t *mask, float *obs_out, void *stream);
+/* step(), :292-442 (+ DummyVecEnv auto-reset when auto_reset != 0) */
+int  finenv_stoploss_step(finenv_stoploss *h, const float *actions, float *obs, float *reward,
+                          uint8_t *done, float *term_obs, int32_t auto_reset, void *stream);
 
 #ifdef __cplusplus
 }
