@@ -132,6 +132,18 @@ def bench_side(args, torch, dev, kind):
                            device=dev)
         B = 4 * N + 2 * (28 + 4 * N) + 4 * (1 + N + W) + 5          # 385
         name, kern = "vectorized CryptoEnv (10 pairs, 4 indicators/pair)", "crypto_kernel"
+    elif kind in ("cashpenalty", "stoploss"):
+        from finrl_amd.vec_cashpenalty import CashPenaltyPanel, VecCashPenaltyEnv, VecStopLossEnv
+        T, N, Cc = N_DAYS, N_TICKERS, 5
+        close = 50 * np.exp(np.cumsum(rng.normal(0, 0.01, (T, N)), axis=0))
+        panel = CashPenaltyPanel(close, rng.normal(0, 10, (T, N, Cc)), np.abs(rng.normal(0, 30, T)))
+        cls = VecCashPenaltyEnv if kind == "cashpenalty" else VecStopLossEnv
+        env = cls(panel, E, hmax=2_000, random_start=True, device=dev)
+        books = 1 if kind == "cashpenalty" else 6
+        # actions + 2 x (cash f64, date/start i32, books f64[N]) + obs + reward/done
+        B = 4 * N + 2 * (16 + 8 * books * N) + 4 * (1 + N + N * Cc) + 5
+        name = f"vectorized {cls.env_name.split('-')[0]} (30 assets x 5 columns, random starts)"
+        kern = f"{kind}_kernel"
     else:
         from finrl_amd.vec_stocknp import VecStockTradingEnvNP
         T, N, K = N_DAYS, N_TICKERS, N_TECH
@@ -169,7 +181,8 @@ def bench_side(args, torch, dev, kind):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--env", default="stock", choices=["stock", "portfolio", "crypto", "stocknp"])
+    ap.add_argument("--env", default="stock", choices=["stock", "portfolio", "crypto", "stocknp", "cashpenalty",
+                                                       "stoploss"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3 * N_DAYS)
     ap.add_argument("--warmup", type=int, default=N_DAYS)
@@ -203,7 +216,7 @@ def main():
     if args.env == "portfolio":
         assert world == 1, "portfolio side-bench is single-GPU"
         return bench_portfolio(args, torch, dev)
-    if args.env in ("crypto", "stocknp"):
+    if args.env in ("crypto", "stocknp", "cashpenalty", "stoploss"):
         assert world == 1, "side benches are single-GPU"
         return bench_side(args, torch, dev, args.env)
 
