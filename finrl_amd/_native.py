@@ -239,6 +239,11 @@ def lib():
     L.finenv_stoploss_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.finenv_stoploss_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    L.finenv_riskpre_returns.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    L.finenv_riskpre_turbulence.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                            C.c_int32, C.c_int32, C.c_void_p]
+    L.finenv_riskpre_rolling_cov.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                             C.c_int32, C.c_void_p]
     if L.finenv_abi_version() != 2:
         raise NativeLibraryError("libfinenv.so ABI version mismatch; rebuild (make -C finrl_amd/csrc)")
     L.finenv_struct_size.argtypes = [C.c_int]

@@ -469,6 +469,33 @@ int  finenv_stoploss_reset(finenv_stoploss *h, const uint8_t *mask, float *obs_o
 int  finenv_stoploss_step(finenv_stoploss *h, const float *actions, float *obs, float *reward,
                           uint8_t *done, float *term_obs, int32_t auto_reset, void *stream);
 
+/* =====================================================================================
+ * Risk precompute that feeds the panels.  Stateless; all buffers are
+ * caller-owned device memory; launches go to `stream`; nothing synchronises.
+ * Floating point (tolerances in tests/test_gpu_riskpre_parity.py): covariance sums run in day
+ * order (NumPy: BLAS), the pseudo-inverse is applied through a Jacobi eigen-decomposition
+ * (NumPy: LAPACK SVD) with NumPy's cutoff 1e-15 * largest eigenvalue.
+ * Contract: complete panel (every asset on every day, close > 0, no NaN).
+ * ===================================================================================== */
+#define FINENV_RISKPRE_MAX_ASSETS 128
+
+/* DataFrame.pct_change() of the close pivot (preprocessors.py:219-221):
+ * returns[t][j] = close[t][j] / close[t-1][j] - 1, row 0 = NaN.  close, returns: [T][N] f64 */
+int finenv_riskpre_returns(const double *close, double *returns, int32_t n_days,
+                           int32_t n_assets, void *stream);
+/* FeatureEngineer.calculate_turbulence (preprocessors.py:215-267): turbulence[t] for all T days
+ * (0 for t < window and for the first two positive values, :247-257).  quad: [T] f64 scratch
+ * (the unfiltered quadratic forms, :244-246).  Needs n_days >= window (the reference raises
+ * otherwise, :260-266) and 2 <= n_assets <= FINENV_RISKPRE_MAX_ASSETS. */
+int finenv_riskpre_turbulence(const double *returns, double *quad, double *turbulence,
+                              int32_t n_days, int32_t n_assets, int32_t window, void *stream);
+/* cov_list of the portfolio-allocation tutorial
+ * (tutorials/2-Advance/FinRL_PortfolioAllocation_Explainable_DRL.py:160-172): cov_out[i-lookback]
+ * = sample covariance of the `lookback` returns ending at day i inclusive, for i in
+ * [lookback, T).  cov_out: [T-lookback][N][N] f64. */
+int finenv_riskpre_rolling_cov(const double *returns, double *cov_out, int32_t n_days,
+                               int32_t n_assets, int32_t lookback, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

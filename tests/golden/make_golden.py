@@ -643,12 +643,79 @@ STOPLOSS_SCENARIOS = {
 }
 
 
+# ----------------------------------------------------------------- turbulence / covariance
+def _load_preprocessors():
+    """finrl.meta.preprocessor.preprocessors behind import shims for the absent third-party
+    modules (stockstats, yfinance) -- the functions used here touch only numpy / pandas."""
+    import importlib
+    import types
+    rh.install()
+    sys.modules.setdefault("stockstats", types.SimpleNamespace(StockDataFrame=object))
+    cfg = types.ModuleType("finrl.config")
+    cfg.INDICATORS = []
+    sys.modules.setdefault("finrl.config", cfg)
+    yd = types.ModuleType("finrl.meta.preprocessor.yahoodownloader")
+    yd.YahooDownloader = object
+    sys.modules.setdefault("finrl.meta.preprocessor.yahoodownloader", yd)
+    sys.modules["finrl"].config = cfg
+    return importlib.import_module("finrl.meta.preprocessor.preprocessors")
+
+
+def run_riskpre(name, *, seed, T, N, sigma=0.012, lookback=252, common=0.6):
+    """FeatureEngineer.calculate_turbulence (unmodified) and the tutorial's cov_list lines
+    (tutorials/2-Advance/FinRL_PortfolioAllocation_Explainable_DRL.py:160-172, the same
+    pandas calls on the same frame) on a synthetic complete panel."""
+    import pandas as pd
+    pre = _load_preprocessors()
+    rng = np.random.default_rng(seed + 7000)
+    market = rng.normal(0, sigma, (T, 1))
+    rets = common * market + rng.normal(0, sigma, (T, N)) * rng.uniform(0.5, 2.0, N)
+    close = 80 * np.exp(np.cumsum(rets, axis=0))
+    tics = [f"TIC{i:03d}" for i in range(N)]
+    dates = pd.bdate_range("2015-01-01", periods=T).strftime("%Y-%m-%d")
+    df = pd.DataFrame({"date": np.repeat(dates, N), "tic": np.tile(tics, T),
+                       "close": close.reshape(-1)})
+    fe = pre.FeatureEngineer(use_technical_indicator=False, use_turbulence=True)
+    turb = fe.calculate_turbulence(df)
+    assert list(turb["date"]) == list(dates)
+    # tutorial :157-172
+    d2 = df.sort_values(["date", "tic"], ignore_index=True)
+    d2.index = d2.date.factorize()[0]
+    cov_list = []
+    for i in range(lookback, len(d2.index.unique())):
+        data_lookback = d2.loc[i - lookback:i, :]
+        price_lookback = data_lookback.pivot_table(index="date", columns="tic", values="close")
+        return_lookback = price_lookback.pct_change().dropna()
+        cov_list.append(return_lookback.cov().values)
+    keep = np.unique(np.concatenate([np.arange(0, len(cov_list), 7), [len(cov_list) - 1]]))
+    out = dict(close=close, turbulence=turb["turbulence"].to_numpy(np.float64),
+               cov_index=keep.astype(np.int64), cov=np.stack([cov_list[k] for k in keep]),
+               lookback=np.int64(lookback),
+               meta=np.array([f"seed={seed}", f"numpy={np.__version__}",
+                              f"pandas={pd.__version__}",
+                              "source=finrl/meta/preprocessor/preprocessors.py:215-267 (unmodified)"
+                              " + tutorial cov_list lines"]))
+    path = os.path.join(HERE, f"riskpre_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB) T={T} N={N} "
+          f"nonzero={int((out['turbulence'] > 0).sum())} max={out['turbulence'].max():.3f}")
+    return out
+
+
+RISKPRE_SCENARIOS = {
+    "dow30": dict(seed=81, T=300, N=30),
+    "small": dict(seed=82, T=280, N=6, sigma=0.02),
+    "wide": dict(seed=83, T=262, N=100, common=0.8),
+}
+
+
 def main(argv):
     names = argv or (list(STOCK_SCENARIOS) + ["portfolio:" + k for k in PORTFOLIO_SCENARIOS]
                      + ["crypto:" + k for k in CRYPTO_SCENARIOS]
                      + ["stocknp:" + k for k in STOCKNP_SCENARIOS]
                      + ["cashpenalty:" + k for k in CASHPENALTY_SCENARIOS]
-                     + ["stoploss:" + k for k in STOPLOSS_SCENARIOS])
+                     + ["stoploss:" + k for k in STOPLOSS_SCENARIOS]
+                     + ["riskpre:" + k for k in RISKPRE_SCENARIOS])
     for n in names:
         if n in STOCK_SCENARIOS:
             run_stock(n, **STOCK_SCENARIOS[n])
@@ -658,6 +725,8 @@ def main(argv):
             run_cashpenalty(n[12:], **CASHPENALTY_SCENARIOS[n[12:]])
         elif n.startswith("stoploss:") and n[9:] in STOPLOSS_SCENARIOS:
             run_stoploss(n[9:], **STOPLOSS_SCENARIOS[n[9:]])
+        elif n.startswith("riskpre:") and n[8:] in RISKPRE_SCENARIOS:
+            run_riskpre(n[8:], **RISKPRE_SCENARIOS[n[8:]])
         elif n.startswith("stocknp:") and n[8:] in STOCKNP_SCENARIOS:
             run_stocknp(n[8:], **STOCKNP_SCENARIOS[n[8:]])
         elif n.startswith("crypto:") and n[7:] in CRYPTO_SCENARIOS:
