@@ -15,16 +15,17 @@ os.environ.setdefault("FINENV_LIB", os.path.join(ROOT, "finrl_amd", "lib", "libf
 
 def main():
     E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+    NT = int(sys.argv[2]) if len(sys.argv) > 2 else 30
     import torch
     import bench
     from finrl_amd import StockPanel, _native as nat
     from finrl_amd.vec_env import VecStockTradingEnv
-    close, tech, risk = bench.synth_panel()
+    close, tech, risk = bench.synth_panel(N=NT)
     env = VecStockTradingEnv(StockPanel(close, tech, risk), E, **bench.ENV_KW)
     env.reset()
     nb = (E + 63) // 64
     buf = torch.zeros(nb * 2 * 16, dtype=torch.int64, device="cuda")
-    pool = [torch.rand(E, 30, device="cuda") * 2 - 1 for _ in range(8)]
+    pool = [torch.rand(E, NT, device="cuda") * 2 - 1 for _ in range(8)]
     for i in range(200):
         env.step(pool[i & 7])
     L = nat.lib()
