@@ -81,20 +81,47 @@ __device__ __forceinline__ void cp_write_rows(float *__restrict__ dst, const CpP
     const bool uniform = __all(!mine || row_day == d0);
     float *const base = dst + (size_t)e0 * D;
     const int nchunk = (D + kWave - 1) / kWave;
+    if (!uniform) {
+        // Per-env panel rows (random starts): 32 rows' loads are issued before the first store of
+        // the batch.  A load placed between stores waits for every older store to be
+        // acknowledged (vmcnt is in-order on gfx950): one exposed round trip per row, 64 per chunk.
+        constexpr int kBatch = 32;
+        for (int k = 0; k < nchunk; ++k) {
+            const int col = k * kWave + lane;
+            const bool in = col < D;
+            const bool head = col <= N;
+            const bool any_head = __any(in && head);
+            for (int g = 0; g < nenv_w; g += kBatch) {
+                float t[kBatch];
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j) {
+                    const int de = __builtin_amdgcn_readlane(row_day, min(g + j, nenv_w - 1));
+                    t[j] = (in && !head) ? *at(p.panel.info, (unsigned)(de * W + col - 1 - N)) : 0.0f;
+                }
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j) {
+                    const int el = g + j;
+                    if (el >= nenv_w || !((lane_mask >> el) & 1ull)) continue;
+                    float v = t[j];
+                    if (any_head) {
+                        const float hv = rows[el * kRow + (head ? col : 0)];
+                        v = head ? hv : v;
+                    }
+                    if (in) *at(base, (unsigned)(el * D + col)) = v;
+                }
+            }
+        }
+        return;
+    }
     for (int k = 0; k < nchunk; ++k) {
         const int col = k * kWave + lane;
         const bool in = col < D;
         const bool head = col <= N;
         const bool any_head = __any(in && head);
-        float t = 0.0f;
-        if (uniform && in && !head) t = *at(p.panel.info, (unsigned)(d0 * W + col - 1 - N));
+        const float t = (in && !head) ? *at(p.panel.info, (unsigned)(d0 * W + col - 1 - N)) : 0.0f;
         for (int el = 0; el < nenv_w; ++el) {
             if (!((lane_mask >> el) & 1ull)) continue;
             float v = t;
-            if (!uniform) {
-                const int de = __builtin_amdgcn_readlane(row_day, el);
-                if (in && !head) v = *at(p.panel.info, (unsigned)(de * W + col - 1 - N));
-            }
             if (any_head) {
                 const float hv = rows[el * kRow + (head ? col : 0)];
                 v = head ? hv : v;
