@@ -22,6 +22,7 @@ constexpr int kWave = 64;
 constexpr int kMaxN = FINENV_CASHPENALTY_MAX_ASSETS;
 constexpr int kRow = kMaxN + 1;
 constexpr int kWaves = 2;
+constexpr int kB = 8;                        // assets per load batch
 constexpr int kLdsPerWave = kWave * kRow + kMaxN * kWave * 2;   // rows + f64 transactions [i][lane]
 
 struct CpParams {
@@ -131,7 +132,51 @@ __device__ __forceinline__ void cp_write_rows(float *__restrict__ dst, const CpP
     }
 }
 
-template <bool RESET_ONLY>
+// Per-env panel rows (random starts), D <= NCH * 64: every load of the wave's 64 rows is issued
+// before the first store (NCH * 64 VGPRs) -- ONE exposed round trip per wave.  A load placed
+// between stores waits for every older store to be acknowledged (vmcnt is in-order on gfx950).
+template <int NCH>
+__device__ __forceinline__ void cp_write_rows_full(float *__restrict__ dst, const CpParams &p, int e0,
+                                                   int nenv_w, int row_day,
+                                                   unsigned long long lane_mask,
+                                                   const float *rows, int lane)
+{
+    const int N = p.cfg.n_assets, D = p.D, W = D - 1 - N;
+    float *const base = dst + (size_t)e0 * D;
+    float t[(NCH > 0 ? NCH : 1) * kWave];
+    if (W > 0) {
+#pragma unroll
+        for (int el = 0; el < kWave; ++el) {
+            const int de = __builtin_amdgcn_readlane(row_day, el);
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const int col = k * kWave + lane;
+                const bool ld = col < D && col > N;
+                t[el * NCH + k] = *at(p.panel.info, (unsigned)(ld ? de * W + col - 1 - N : 0));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NCH * kWave; ++j) t[j] = 0.0f;
+    }
+#pragma unroll
+    for (int el = 0; el < kWave; ++el) {
+        if (el >= nenv_w || !((lane_mask >> el) & 1ull)) continue;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int col = k * kWave + lane;
+            float v = t[el * NCH + k];
+            if (k == 0) {                       // N <= 32: cash / holdings sit in chunk 0 only
+                const bool head = col <= N;
+                const float hv = rows[el * kRow + (head ? col : 0)];
+                v = head ? hv : v;
+            }
+            if (col < D) *at(base, (unsigned)(el * D + col)) = v;
+        }
+    }
+}
+
+template <bool RESET_ONLY, int NCH>
 __global__ void __launch_bounds__(kWave *kWaves) cashpenalty_kernel(const CpParams p)
 {
     __shared__ __attribute__((aligned(16))) float lds_all[kWaves * kLdsPerWave];
@@ -195,28 +240,41 @@ __global__ void __launch_bounds__(kWave *kWaves) cashpenalty_kernel(const CpPara
     double asset_value = 0.0, proceeds = 0.0, spend = 0.0;
     for (int i = 0; i < N; ++i) sum_trades += fabs((double)row[i]);              // :293
     if (!at_end) {
-        for (int i = 0; i < N; ++i) {
-            const double h = KH(i);
-            const double cl = *at(p.panel.close, cb + (unsigned)i);
-            asset_value += h * cl;                                               // np.dot, :310
-            const float a32 = row[i] * hmaxf;                                    // :257 (float32)
-            const float a = cl > 0.0 ? a32 : 0.0f;                               // :260
-            double tr;
-            if (c.discrete_actions) {                                            // :263-274
-                long long q = (long long)cp_floordiv((double)a, cl);
-                const long long inc = c.shares_increment;
-                const long long num = q >= 0 ? q : q + inc;
-                long long fq = num / inc;
-                if ((num % inc != 0) && ((num < 0) != (inc < 0))) fq -= 1;
-                tr = (double)(fq * inc);
-            } else {
-                tr = (double)a / cl;                                             // :276
+        // batches of kB assets, the batch's global loads issued first (a rolled loop exposes one
+        // HBM round trip per asset at one wave per SIMD)
+        for (int i0 = 0; i0 < N; i0 += kB) {
+            double hb[kB], clb[kB];
+#pragma unroll
+            for (int j = 0; j < kB; ++j) {
+                const int i = min(i0 + j, N - 1);
+                hb[j] = KH(i);
+                clb[j] = *at(p.panel.close, cb + (unsigned)i);
             }
-            tr = fmax(tr, -h);                                                   // :279
-            tr = turbulent ? -h : tr;                                            // :282-287
-            trl[i * kWave + lane] = tr;
-            proceeds += (tr < 0.0 ? -tr : 0.0) * cl;                             // :323-324
-            spend += (tr > 0.0 ? tr : 0.0) * cl;                                 // :328-329
+#pragma unroll
+            for (int j = 0; j < kB; ++j) {
+                const int i = i0 + j;
+                if (i >= N) break;
+                const double h = hb[j], cl = clb[j];
+                asset_value += h * cl;                                           // np.dot, :310
+                const float a32 = row[i] * hmaxf;                                // :257 (float32)
+                const float a = cl > 0.0 ? a32 : 0.0f;                           // :260
+                double tr;
+                if (c.discrete_actions) {                                        // :263-274
+                    long long q = (long long)cp_floordiv((double)a, cl);
+                    const long long inc = c.shares_increment;
+                    const long long num = q >= 0 ? q : q + inc;
+                    long long fq = num / inc;
+                    if ((num % inc != 0) && ((num < 0) != (inc < 0))) fq -= 1;
+                    tr = (double)(fq * inc);
+                } else {
+                    tr = (double)a / cl;                                         // :276
+                }
+                tr = fmax(tr, -h);                                               // :279
+                tr = turbulent ? -h : tr;                                        // :282-287
+                trl[i * kWave + lane] = tr;
+                proceeds += (tr < 0.0 ? -tr : 0.0) * cl;                         // :323-324
+                spend += (tr > 0.0 ? tr : 0.0) * cl;                             // :328-329
+            }
         }
         logged_cash = coh;                                                       // :312-314
         logged_total = coh + asset_value;
@@ -242,11 +300,19 @@ __global__ void __launch_bounds__(kWave *kWaves) cashpenalty_kernel(const CpPara
     const bool advance = !done;
     if (advance) {
         coh = coh_new;
-        for (int i = 0; i < N; ++i) {
-            const double tr = trl[i * kWave + lane];
-            const double hn = KH(i) + ((tr > 0.0 && !keep_buys) ? 0.0 : tr);     // :352
-            if (valid) KH(i) = hn;
-            row[1 + i] = (float)hn;
+        for (int i0 = 0; i0 < N; i0 += kB) {
+            double hb[kB];
+#pragma unroll
+            for (int j = 0; j < kB; ++j) hb[j] = KH(min(i0 + j, N - 1));
+#pragma unroll
+            for (int j = 0; j < kB; ++j) {
+                const int i = i0 + j;
+                if (i >= N) break;
+                const double tr = trl[i * kWave + lane];
+                const double hn = hb[j] + ((tr > 0.0 && !keep_buys) ? 0.0 : tr); // :352
+                if (valid) KH(i) = hn;
+                row[1 + i] = (float)hn;
+            }
         }
         di += 1;                                                                 // :353
         if (c.use_turbulence) turb = *at(p.panel.turb, (unsigned)di);            // :354-357
@@ -290,7 +356,15 @@ __global__ void __launch_bounds__(kWave *kWaves) cashpenalty_kernel(const CpPara
             wave_sync();
         }
     }
-    cp_write_rows(p.obs, p, e0, nenv_w, row_day, valid_mask, rows, lane);
+    bool rows_done = false;
+    if (NCH > 0) {
+        const int d0 = __builtin_amdgcn_readfirstlane(row_day);
+        if (!__all(row_day == d0)) {
+            cp_write_rows_full<NCH>(p.obs, p, e0, nenv_w, row_day, valid_mask, rows, lane);
+            rows_done = true;
+        }
+    }
+    if (!rows_done) cp_write_rows(p.obs, p, e0, nenv_w, row_day, valid_mask, rows, lane);
     if (valid) {
         KF(FINENV_KF_COH) = coh;
         KI(FINENV_KI_DATE_INDEX) = di;
@@ -396,7 +470,7 @@ int finenv_cashpenalty_reset(finenv_cashpenalty *h, const uint8_t *mask, float *
     CpParams p = kp_params(h);
     p.mask = mask;
     p.obs = obs_out;
-    hipLaunchKernelGGL((cashpenalty_kernel<true>), kp_grid(h->cfg.n_envs), dim3(kWave * kWaves),
+    hipLaunchKernelGGL((cashpenalty_kernel<true, 0>), kp_grid(h->cfg.n_envs), dim3(kWave * kWaves),
                        0, (hipStream_t)stream, p);
     return kp_check(h, "cashpenalty_reset");
 }
@@ -416,8 +490,13 @@ int finenv_cashpenalty_step(finenv_cashpenalty *h, const float *actions, float *
     p.done = done;
     p.term_obs = term_obs;
     p.auto_reset = auto_reset;
-    hipLaunchKernelGGL((cashpenalty_kernel<false>), kp_grid(h->cfg.n_envs), dim3(kWave * kWaves),
-                       0, (hipStream_t)stream, p);
+    const dim3 grid = kp_grid(h->cfg.n_envs), block(kWave * kWaves);
+    switch ((h->D + kWave - 1) / kWave) {      // chunks per observation row
+    case 1: hipLaunchKernelGGL((cashpenalty_kernel<false, 1>), grid, block, 0, (hipStream_t)stream, p); break;
+    case 2: hipLaunchKernelGGL((cashpenalty_kernel<false, 2>), grid, block, 0, (hipStream_t)stream, p); break;
+    case 3: hipLaunchKernelGGL((cashpenalty_kernel<false, 3>), grid, block, 0, (hipStream_t)stream, p); break;
+    default: hipLaunchKernelGGL((cashpenalty_kernel<false, 0>), grid, block, 0, (hipStream_t)stream, p); break;
+    }
     return kp_check(h, "cashpenalty_step");
 }
 

@@ -24,6 +24,7 @@ constexpr int kWave = 64;
 constexpr int kMaxN = FINENV_STOPLOSS_MAX_ASSETS;
 constexpr int kRow = kMaxN + 1;
 constexpr int kWaves = 2;
+constexpr int kB = 8;                        // assets per load batch
 constexpr int kLdsPerWave = kWave * kRow + kMaxN * kWave * 2;   // rows + f64 transactions [i][lane]
 
 struct SlParams {
@@ -138,7 +139,51 @@ __device__ __forceinline__ void sl_write_rows(float *__restrict__ dst, const SlP
     }
 }
 
-template <bool RESET_ONLY>
+// Per-env panel rows (random starts), D <= NCH * 64: every load of the wave's 64 rows is issued
+// before the first store (NCH * 64 VGPRs) -- ONE exposed round trip per wave.  A load placed
+// between stores waits for every older store to be acknowledged (vmcnt is in-order on gfx950).
+template <int NCH>
+__device__ __forceinline__ void sl_write_rows_full(float *__restrict__ dst, const SlParams &p, int e0,
+                                                   int nenv_w, int row_day,
+                                                   unsigned long long lane_mask,
+                                                   const float *rows, int lane)
+{
+    const int N = p.cfg.n_assets, D = p.D, W = D - 1 - N;
+    float *const base = dst + (size_t)e0 * D;
+    float t[(NCH > 0 ? NCH : 1) * kWave];
+    if (W > 0) {
+#pragma unroll
+        for (int el = 0; el < kWave; ++el) {
+            const int de = __builtin_amdgcn_readlane(row_day, el);
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const int col = k * kWave + lane;
+                const bool ld = col < D && col > N;
+                t[el * NCH + k] = *at(p.panel.info, (unsigned)(ld ? de * W + col - 1 - N : 0));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NCH * kWave; ++j) t[j] = 0.0f;
+    }
+#pragma unroll
+    for (int el = 0; el < kWave; ++el) {
+        if (el >= nenv_w || !((lane_mask >> el) & 1ull)) continue;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int col = k * kWave + lane;
+            float v = t[el * NCH + k];
+            if (k == 0) {                       // N <= 32: cash / holdings sit in chunk 0 only
+                const bool head = col <= N;
+                const float hv = rows[el * kRow + (head ? col : 0)];
+                v = head ? hv : v;
+            }
+            if (col < D) *at(base, (unsigned)(el * D + col)) = v;
+        }
+    }
+}
+
+template <bool RESET_ONLY, int NCH>
 __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams p)
 {
     __shared__ __attribute__((aligned(16))) float lds_all[kWaves * kLdsPerWave];
@@ -199,14 +244,26 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
 
     // ---- pass 1: reward terms of the state as the previous step left it (:313 / :304) ---------
     double slp_sum = 0.0, lpp_sum = 0.0, add = 0.0;
-    for (int i = 0; i < N; ++i) {
-        sum_trades += fabs((double)row[i]);                                      // :294
-        const double h = LV(FINENV_LV_HOLDINGS, i);
-        const double ps = LV(FINENV_LV_PROFIT_SELL_DIFF_AVG_BUY, i);
-        slp_sum += LV(FINENV_LV_PREV_HOLDINGS, i) *
-                   fmin(LV(FINENV_LV_CLOSING_DIFF_AVG_BUY, i), 0.0);             // :262,:273-275
-        lpp_sum += h * fmin(ps, 0.0);                                            // :263-265,:278-280
-        add += h * fmax(ps, 0.0);                                                // :266-268,:283
+    // (every per-asset loop below runs in batches of kB assets with the batch's global loads issued
+    //  first: a rolled loop exposes one HBM round trip per asset at one wave per SIMD)
+    for (int i0 = 0; i0 < N; i0 += kB) {
+        double hh[kB], ps[kB], ph[kB], cd[kB];
+#pragma unroll
+        for (int j = 0; j < kB; ++j) {
+            const int i = min(i0 + j, N - 1);
+            hh[j] = LV(FINENV_LV_HOLDINGS, i);
+            ps[j] = LV(FINENV_LV_PROFIT_SELL_DIFF_AVG_BUY, i);
+            ph[j] = LV(FINENV_LV_PREV_HOLDINGS, i);
+            cd[j] = LV(FINENV_LV_CLOSING_DIFF_AVG_BUY, i);
+        }
+#pragma unroll
+        for (int j = 0; j < kB; ++j) {
+            if (i0 + j >= N) break;
+            sum_trades += fabs((double)row[i0 + j]);                             // :294
+            slp_sum += ph[j] * fmin(cd[j], 0.0);                                 // :262,:273-275
+            lpp_sum += hh[j] * fmin(ps[j], 0.0);                                 // :263-265,:278-280
+            add += hh[j] * fmax(ps[j], 0.0);                                     // :266-268,:283
+        }
     }
     double reward = sl_reward(c, step, logged_total, logged_cash, slp_sum, lpp_sum, add);
     bool done = at_end;
@@ -219,33 +276,45 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
     bool keep_buys = true;
     double coh_new = coh;
     if (!at_end) {
-        for (int i = 0; i < N; ++i) {
-            const double h = LV(FINENV_LV_HOLDINGS, i);
-            const double cl = *at(p.panel.close, cb + (unsigned)i);
-            const double abp = LV(FINENV_LV_AVG_BUY_PRICE, i);
-            asset_value += h * cl;                                               // :311
-            const float a32 = row[i] * hmaxf;                                    // :321 (float32)
-            double a = cl > 0.0 ? (double)a32 : 0.0;                             // :326
-            a = turbulent ? -(h * cl) : a;                                       // :327-331
-            double tr;
-            if (c.discrete_actions) {                                            // :333-343
-                long long q = cl > 0.0 ? (long long)sl_floordiv(a, cl) : 0ll;
-                const long long inc = c.shares_increment;
-                const long long num = q >= 0 ? q : q + inc;
-                long long fq = num / inc;
-                if ((num % inc != 0) && ((num < 0) != (inc < 0))) fq -= 1;
-                tr = (double)(fq * inc);
-            } else {
-                tr = cl > 0.0 ? a / cl : 0.0;                                    // :345
+        for (int i0 = 0; i0 < N; i0 += kB) {
+            double hb[kB], clb[kB], ab[kB], pb[kB];
+#pragma unroll
+            for (int j = 0; j < kB; ++j) {
+                const int i = min(i0 + j, N - 1);
+                hb[j] = LV(FINENV_LV_HOLDINGS, i);
+                clb[j] = *at(p.panel.close, cb + (unsigned)i);
+                ab[j] = LV(FINENV_LV_AVG_BUY_PRICE, i);
+                pb[j] = LV(FINENV_LV_PREV_HOLDINGS, i);
             }
-            tr = fmax(tr, -h);                                                   // :348
-            const double cd = cl - (c.stoploss_penalty * abp);                   // :350-352
-            if (valid) LV(FINENV_LV_CLOSING_DIFF_AVG_BUY, i) = cd;
-            slp_new += LV(FINENV_LV_PREV_HOLDINGS, i) * fmin(cd, 0.0);
-            tr = (stop_armed && cd < 0.0) ? -h : tr;                             // :353-357
-            trl[i * kWave + lane] = tr;
-            proceeds += (tr < 0.0 ? -tr : 0.0) * cl;                             // :363-364
-            spend += (tr > 0.0 ? tr : 0.0) * cl;                                 // :368-369
+#pragma unroll
+            for (int j = 0; j < kB; ++j) {
+                const int i = i0 + j;
+                if (i >= N) break;
+                const double h = hb[j], cl = clb[j], abp = ab[j];
+                asset_value += h * cl;                                           // :311
+                const float a32 = row[i] * hmaxf;                                // :321 (float32)
+                double a = cl > 0.0 ? (double)a32 : 0.0;                         // :326
+                a = turbulent ? -(h * cl) : a;                                   // :327-331
+                double tr;
+                if (c.discrete_actions) {                                        // :333-343
+                    long long q = cl > 0.0 ? (long long)sl_floordiv(a, cl) : 0ll;
+                    const long long inc = c.shares_increment;
+                    const long long num = q >= 0 ? q : q + inc;
+                    long long fq = num / inc;
+                    if ((num % inc != 0) && ((num < 0) != (inc < 0))) fq -= 1;
+                    tr = (double)(fq * inc);
+                } else {
+                    tr = cl > 0.0 ? a / cl : 0.0;                                // :345
+                }
+                tr = fmax(tr, -h);                                               // :348
+                const double cd = cl - (c.stoploss_penalty * abp);               // :350-352
+                if (valid) LV(FINENV_LV_CLOSING_DIFF_AVG_BUY, i) = cd;
+                slp_new += pb[j] * fmin(cd, 0.0);
+                tr = (stop_armed && cd < 0.0) ? -h : tr;                         // :353-357
+                trl[i * kWave + lane] = tr;
+                proceeds += (tr < 0.0 ? -tr : 0.0) * cl;                         // :363-364
+                spend += (tr > 0.0 ? tr : 0.0) * cl;                             // :368-369
+            }
         }
         logged_cash = coh;                                                       // :315-317
         logged_total = coh + asset_value;
@@ -270,34 +339,46 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
     if (advance) {
         coh = coh_new;
         double ntr = 0.0;
-        for (int i = 0; i < N; ++i) {
-            const double tr0 = trl[i * kWave + lane];
-            const double cl = *at(p.panel.close, cb + (unsigned)i);
-            const double h = LV(FINENV_LV_HOLDINGS, i);
-            double abp = LV(FINENV_LV_AVG_BUY_PRICE, i);
-            double nb = LV(FINENV_LV_N_BUYS, i);
-            const bool sold = tr0 < 0.0;                                         // sells > 0
-            const bool bought = tr0 > 0.0;                                       // buys > 0 (:418)
-            const double tr = (bought && !keep_buys) ? 0.0 : tr0;                // :376
-            const double scp = sold ? cl : 0.0;                                  // :388-390
-            const bool profit = scp - abp > 0.0;                                 // :391-393
-            const double ps = profit ? cl - (c.min_profit_penalty * abp) : 0.0;  // :395-399
-            ntr += tr != 0.0 ? 1.0 : 0.0;                                        // :411
-            const double hu = h + tr;                                            // :415
-            nb += bought ? 1.0 : 0.0;                                            // :419
-            const double abp_new = abp + ((cl - abp) / nb);                      // :420-424
-            abp = bought ? abp_new : abp;
-            const bool held = hu > 0.0;                                          // :427-428
-            nb = held ? nb : 0.0;
-            abp = held ? abp : 0.0;
-            if (valid) {
-                LV(FINENV_LV_PROFIT_SELL_DIFF_AVG_BUY, i) = ps;
-                LV(FINENV_LV_PREV_HOLDINGS, i) = h;
-                LV(FINENV_LV_HOLDINGS, i) = hu;
-                LV(FINENV_LV_N_BUYS, i) = nb;
-                LV(FINENV_LV_AVG_BUY_PRICE, i) = abp;
+        for (int i0 = 0; i0 < N; i0 += kB) {
+            double hb[kB], clb[kB], ab[kB], nbb[kB];
+#pragma unroll
+            for (int j = 0; j < kB; ++j) {
+                const int i = min(i0 + j, N - 1);
+                clb[j] = *at(p.panel.close, cb + (unsigned)i);
+                hb[j] = LV(FINENV_LV_HOLDINGS, i);
+                ab[j] = LV(FINENV_LV_AVG_BUY_PRICE, i);
+                nbb[j] = LV(FINENV_LV_N_BUYS, i);
             }
-            row[1 + i] = (float)hu;
+#pragma unroll
+            for (int j = 0; j < kB; ++j) {
+                const int i = i0 + j;
+                if (i >= N) break;
+                const double tr0 = trl[i * kWave + lane];
+                const double cl = clb[j], h = hb[j];
+                double abp = ab[j], nb = nbb[j];
+                const bool sold = tr0 < 0.0;                                     // sells > 0
+                const bool bought = tr0 > 0.0;                                   // buys > 0 (:418)
+                const double tr = (bought && !keep_buys) ? 0.0 : tr0;            // :376
+                const double scp = sold ? cl : 0.0;                              // :388-390
+                const bool profit = scp - abp > 0.0;                             // :391-393
+                const double ps = profit ? cl - (c.min_profit_penalty * abp) : 0.0;  // :395-399
+                ntr += tr != 0.0 ? 1.0 : 0.0;                                    // :411
+                const double hu = h + tr;                                        // :415
+                nb += bought ? 1.0 : 0.0;                                        // :419
+                const double abp_new = abp + ((cl - abp) / nb);                  // :420-424
+                abp = bought ? abp_new : abp;
+                const bool held = hu > 0.0;                                      // :427-428
+                nb = held ? nb : 0.0;
+                abp = held ? abp : 0.0;
+                if (valid) {
+                    LV(FINENV_LV_PROFIT_SELL_DIFF_AVG_BUY, i) = ps;
+                    LV(FINENV_LV_PREV_HOLDINGS, i) = h;
+                    LV(FINENV_LV_HOLDINGS, i) = hu;
+                    LV(FINENV_LV_N_BUYS, i) = nb;
+                    LV(FINENV_LV_AVG_BUY_PRICE, i) = abp;
+                }
+                row[1 + i] = (float)hu;
+            }
         }
         actual_num_trades = ntr;
         di += 1;                                                                 // :430
@@ -342,7 +423,15 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
             wave_sync();
         }
     }
-    sl_write_rows(p.obs, p, e0, nenv_w, row_day, valid_mask, rows, lane);
+    bool rows_done = false;
+    if (NCH > 0) {
+        const int d0 = __builtin_amdgcn_readfirstlane(row_day);
+        if (!__all(row_day == d0)) {
+            sl_write_rows_full<NCH>(p.obs, p, e0, nenv_w, row_day, valid_mask, rows, lane);
+            rows_done = true;
+        }
+    }
+    if (!rows_done) sl_write_rows(p.obs, p, e0, nenv_w, row_day, valid_mask, rows, lane);
     if (valid) {
         LF(FINENV_LF_COH) = coh;
         LI(FINENV_LI_DATE_INDEX) = di;
@@ -447,7 +536,7 @@ int finenv_stoploss_reset(finenv_stoploss *h, const uint8_t *mask, float *obs_ou
     SlParams p = sl_params(h);
     p.mask = mask;
     p.obs = obs_out;
-    hipLaunchKernelGGL((stoploss_kernel<true>), sl_grid(h->cfg.n_envs), dim3(kWave * kWaves), 0,
+    hipLaunchKernelGGL((stoploss_kernel<true, 0>), sl_grid(h->cfg.n_envs), dim3(kWave * kWaves), 0,
                        (hipStream_t)stream, p);
     return sl_check(h, "stoploss_reset");
 }
@@ -466,8 +555,13 @@ int finenv_stoploss_step(finenv_stoploss *h, const float *actions, float *obs, f
     p.done = done;
     p.term_obs = term_obs;
     p.auto_reset = auto_reset;
-    hipLaunchKernelGGL((stoploss_kernel<false>), sl_grid(h->cfg.n_envs), dim3(kWave * kWaves), 0,
-                       (hipStream_t)stream, p);
+    const dim3 grid = sl_grid(h->cfg.n_envs), block(kWave * kWaves);
+    switch ((h->D + kWave - 1) / kWave) {      // chunks per observation row
+    case 1: hipLaunchKernelGGL((stoploss_kernel<false, 1>), grid, block, 0, (hipStream_t)stream, p); break;
+    case 2: hipLaunchKernelGGL((stoploss_kernel<false, 2>), grid, block, 0, (hipStream_t)stream, p); break;
+    case 3: hipLaunchKernelGGL((stoploss_kernel<false, 3>), grid, block, 0, (hipStream_t)stream, p); break;
+    default: hipLaunchKernelGGL((stoploss_kernel<false, 0>), grid, block, 0, (hipStream_t)stream, p); break;
+    }
     return sl_check(h, "stoploss_step");
 }
 

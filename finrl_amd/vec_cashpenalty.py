@@ -137,8 +137,7 @@ class VecCashPenaltyEnv:
     def _draw_starts(self):
         import torch
         hi = max(1, int(self.panel.T * 0.5))
-        self.state["next_start"].copy_(torch.randint(
-            0, hi, (self.num_envs,), generator=self._gen, device=self.device).to(torch.int32))
+        self.state["next_start"].random_(0, hi, generator=self._gen)     # one in-place kernel
 
     def reset(self, mask=None):
         import torch
