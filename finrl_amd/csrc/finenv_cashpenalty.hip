@@ -74,62 +74,11 @@ __device__ __forceinline__ void cp_write_rows(float *__restrict__ dst, const CpP
                                               unsigned long long lane_mask, const float *rows,
                                               int lane)
 {
-    if (lane_mask == 0ull) return;
     const int N = p.cfg.n_assets, D = p.D, W = D - 1 - N;
-    const int first = __builtin_ctzll(lane_mask);
-    const int d0 = __builtin_amdgcn_readlane(row_day, first);
-    const bool mine = (lane_mask >> lane) & 1ull;
-    const bool uniform = __all(!mine || row_day == d0);
-    float *const base = dst + (size_t)e0 * D;
-    const int nchunk = (D + kWave - 1) / kWave;
-    if (!uniform) {
-        // Per-env panel rows (random starts): 32 rows' loads are issued before the first store of
-        // the batch.  A load placed between stores waits for every older store to be
-        // acknowledged (vmcnt is in-order on gfx950): one exposed round trip per row, 64 per chunk.
-        constexpr int kBatch = 32;
-        for (int k = 0; k < nchunk; ++k) {
-            const int col = k * kWave + lane;
-            const bool in = col < D;
-            const bool head = col <= N;
-            const bool any_head = __any(in && head);
-            for (int g = 0; g < nenv_w; g += kBatch) {
-                float t[kBatch];
-#pragma unroll
-                for (int j = 0; j < kBatch; ++j) {
-                    const int de = __builtin_amdgcn_readlane(row_day, min(g + j, nenv_w - 1));
-                    t[j] = (in && !head) ? *at(p.panel.info, (unsigned)(de * W + col - 1 - N)) : 0.0f;
-                }
-#pragma unroll
-                for (int j = 0; j < kBatch; ++j) {
-                    const int el = g + j;
-                    if (el >= nenv_w || !((lane_mask >> el) & 1ull)) continue;
-                    float v = t[j];
-                    if (any_head) {
-                        const float hv = rows[el * kRow + (head ? col : 0)];
-                        v = head ? hv : v;
-                    }
-                    if (in) *at(base, (unsigned)(el * D + col)) = v;
-                }
-            }
-        }
-        return;
-    }
-    for (int k = 0; k < nchunk; ++k) {
-        const int col = k * kWave + lane;
-        const bool in = col < D;
-        const bool head = col <= N;
-        const bool any_head = __any(in && head);
-        const float t = (in && !head) ? *at(p.panel.info, (unsigned)(d0 * W + col - 1 - N)) : 0.0f;
-        for (int el = 0; el < nenv_w; ++el) {
-            if (!((lane_mask >> el) & 1ull)) continue;
-            float v = t;
-            if (any_head) {
-                const float hv = rows[el * kRow + (head ? col : 0)];
-                v = head ? hv : v;
-            }
-            if (in) *at(base, (unsigned)(el * D + col)) = v;
-        }
-    }
+    write_obs_rows_generic<8, 32>(
+        dst, W > 0 ? p.panel.info : nullptr, D, e0, nenv_w, row_day, lane_mask, rows, kRow, lane,
+        [=](int day, int col) { return day * W + col - 1 - N; },
+        [=](int col) { return col <= N ? col : -1; });
 }
 
 // Per-env panel rows (random starts), D <= NCH * 64: every load of the wave's 64 rows is issued
@@ -159,6 +108,8 @@ __device__ __forceinline__ void cp_write_rows_full(float *__restrict__ dst, cons
 #pragma unroll
         for (int j = 0; j < NCH * kWave; ++j) t[j] = 0.0f;
     }
+#pragma unroll
+    for (int j = 0; j < NCH * kWave; ++j) pin(t[j]);
 #pragma unroll
     for (int el = 0; el < kWave; ++el) {
         if (el >= nenv_w || !((lane_mask >> el) & 1ull)) continue;
@@ -214,14 +165,7 @@ __global__ void __launch_bounds__(kWave *kWaves) cashpenalty_kernel(const CpPara
     }
 
     // ---- action tile -> LDS rows --------------------------------------------------------------
-    {
-        const float *__restrict__ src = p.actions + (size_t)e0 * N;
-        const int total = nenv_w * N;
-        for (int f = lane; f < total; f += kWave) {
-            const int el = (N == 1) ? f : (int)__umulhi((unsigned)f, p.magicN);
-            rows[el * kRow + (f - el * N)] = *at(src, (unsigned)f);
-        }
-    }
+    stage_action_tile(rows, kRow, p.actions + (size_t)e0 * N, nenv_w, N, p.magicN, lane);
     int di = KI(FINENV_KI_DATE_INDEX);
     const int start = KI(FINENV_KI_START);
     double coh = KF(FINENV_KF_COH);
@@ -250,6 +194,8 @@ __global__ void __launch_bounds__(kWave *kWaves) cashpenalty_kernel(const CpPara
                 hb[j] = KH(i);
                 clb[j] = *at(p.panel.close, cb + (unsigned)i);
             }
+#pragma unroll
+            for (int j = 0; j < kB; ++j) { pin(hb[j]); pin(clb[j]); }
 #pragma unroll
             for (int j = 0; j < kB; ++j) {
                 const int i = i0 + j;
@@ -304,6 +250,8 @@ __global__ void __launch_bounds__(kWave *kWaves) cashpenalty_kernel(const CpPara
             double hb[kB];
 #pragma unroll
             for (int j = 0; j < kB; ++j) hb[j] = KH(min(i0 + j, N - 1));
+#pragma unroll
+            for (int j = 0; j < kB; ++j) pin(hb[j]);
 #pragma unroll
             for (int j = 0; j < kB; ++j) {
                 const int i = i0 + j;

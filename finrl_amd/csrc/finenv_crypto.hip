@@ -70,37 +70,16 @@ __device__ __forceinline__ void cr_write_rows(float *__restrict__ dst, const CrP
                                               unsigned long long lane_mask, const float *rows,
                                               int lane)
 {
-    if (lane_mask == 0ull) return;
     const int N = p.cfg.n_assets, W = p.cfg.n_tech, D = p.D;
-    const int first = __builtin_ctzll(lane_mask);
-    const int t0 = __builtin_amdgcn_readlane(t_row, first);
-    const bool mine = (lane_mask >> lane) & 1ull;
-    const bool uniform = __all(!mine || t_row == t0);
-    float *const base = dst + (size_t)e0 * D;
-    const int nchunk = (D + kWave - 1) / kWave;
-    for (int k = 0; k < nchunk; ++k) {
-        const int col = k * kWave + lane;
-        const bool in = col < D;
-        const bool head = col < 1 + N;
-        const int c2 = in && !head ? col - 1 - N : 0;
-        const int l = (W == 1) ? c2 : (int)__umulhi((unsigned)c2, p.magicW);
-        const int j = c2 - l * W;
-        float t = 0.0f;
-        if (uniform && in && !head) t = *at(p.panel.tech_scaled, (unsigned)((t0 - l) * W + j));
-        for (int el = 0; el < nenv_w; ++el) {
-            if (!((lane_mask >> el) & 1ull)) continue;
-            float v = t;
-            if (!uniform) {
-                const int te = __builtin_amdgcn_readlane(t_row, el);
-                if (in && !head) v = *at(p.panel.tech_scaled, (unsigned)((te - l) * W + j));
-            }
-            if (k == 0) {
-                const float hv = rows[el * kRow + (head ? col : 0)];
-                v = head ? hv : v;
-            }
-            if (in) *at(base, (unsigned)(el * D + col)) = v;
-        }
-    }
+    const unsigned magicW = p.magicW;
+    write_obs_rows_generic<8, 16>(
+        dst, p.panel.tech_scaled, D, e0, nenv_w, t_row, lane_mask, rows, kRow, lane,
+        [=](int t, int col) {                                // lookback row l, indicator j
+            const int c2 = col - 1 - N;
+            const int l = (W == 1) ? c2 : (int)__umulhi((unsigned)c2, magicW);
+            return (t - l) * W + (c2 - l * W);
+        },
+        [=](int col) { return col < 1 + N ? col : -1; });
 }
 
 template <bool RESET_ONLY>
@@ -137,14 +116,7 @@ __global__ void __launch_bounds__(kWave *kWaves) crypto_kernel(const CrParams p)
     }
 
     // ---- action tile [nenv_w][N]: coalesced read, transposed through LDS ------------------
-    {
-        const float *__restrict__ src = p.actions + (size_t)e0 * N;
-        const int total = nenv_w * N;
-        for (int f = lane; f < total; f += kWave) {
-            const int el = (N == 1) ? f : (int)__umulhi((unsigned)f, p.magicN);
-            rows[el * kRow + (f - el * N)] = *at(src, (unsigned)f);
-        }
-    }
+    stage_action_tile(rows, kRow, p.actions + (size_t)e0 * N, nenv_w, N, p.magicN, lane);
     double cash = CF(FINENV_CF_CASH);
     const double prev_asset = CF(FINENV_CF_TOTAL_ASSET);
     double gamma_ret = CF(FINENV_CF_GAMMA_RETURN);
@@ -154,31 +126,64 @@ __global__ void __launch_bounds__(kWave *kWaves) crypto_kernel(const CrParams p)
     wave_sync();
 
     // normalised actions (f32 <- f64 product, :63-65) and holdings -> LDS
-    for (int i = 0; i < N; ++i) {
-        row[i] = (float)((double)row[i] * p.panel.norm[i]);
-        stk[i * kWave + lane] = STK(i);
-    }
-    const double one_m_cs = 1 - p.cfg.sell_cost_pct, one_p_cb = 1 + p.cfg.buy_cost_pct;
-    for (int i = 0; i < N; ++i) {                                             // sells :67-71
-        const float a = row[i];
-        const double pr = *at(p.panel.price, pb + (unsigned)i);
-        if (a < 0.0f && pr > 0.0) {
-            const float s = stk[i * kWave + lane];
-            const float want = -a;
-            const float sell = (want < s) ? want : s;                         // min(stocks, -a)
-            stk[i * kWave + lane] = s - sell;
-            cash += pr * (double)sell * one_m_cs;
+    // (global loads in batches of kPB issued before their first use: a rolled loop exposes one
+    //  HBM round trip per asset at few waves per SIMD)
+    constexpr int kPB = 16;
+    for (int i0 = 0; i0 < N; i0 += kPB) {
+        float sv[kPB];
+#pragma unroll
+        for (int j = 0; j < kPB; ++j) sv[j] = STK(min(i0 + j, N - 1));
+#pragma unroll
+        for (int j = 0; j < kPB; ++j) pin(sv[j]);
+#pragma unroll
+        for (int j = 0; j < kPB; ++j) {
+            const int i = i0 + j;
+            if (i >= N) break;
+            row[i] = (float)((double)row[i] * p.panel.norm[i]);
+            stk[i * kWave + lane] = sv[j];
         }
     }
-    for (int i = 0; i < N; ++i) {                                             // buys :73-77
-        const float a = row[i];
-        const double pr = *at(p.panel.price, pb + (unsigned)i);
-        if (a > 0.0f && pr > 0.0) {
-            const double avail = cr_floordiv(cash, pr);                       // cash // price
-            const double buy = ((double)a < avail) ? (double)a : avail;       // min(avail, a)
-            const float s = stk[i * kWave + lane];
-            stk[i * kWave + lane] = (float)((double)s + buy);
-            cash -= pr * buy * one_p_cb;
+    const double one_m_cs = 1 - p.cfg.sell_cost_pct, one_p_cb = 1 + p.cfg.buy_cost_pct;
+    for (int i0 = 0; i0 < N; i0 += kPB) {                                     // sells :67-71
+        double prb[kPB];
+#pragma unroll
+        for (int j = 0; j < kPB; ++j) prb[j] = *at(p.panel.price, pb + (unsigned)min(i0 + j, N - 1));
+#pragma unroll
+        for (int j = 0; j < kPB; ++j) pin(prb[j]);
+#pragma unroll
+        for (int j = 0; j < kPB; ++j) {
+            const int i = i0 + j;
+            if (i >= N) break;
+            const float a = row[i];
+            const double pr = prb[j];
+            if (a < 0.0f && pr > 0.0) {
+                const float s = stk[i * kWave + lane];
+                const float want = -a;
+                const float sell = (want < s) ? want : s;                     // min(stocks, -a)
+                stk[i * kWave + lane] = s - sell;
+                cash += pr * (double)sell * one_m_cs;
+            }
+        }
+    }
+    for (int i0 = 0; i0 < N; i0 += kPB) {                                     // buys :73-77
+        double prb[kPB];
+#pragma unroll
+        for (int j = 0; j < kPB; ++j) prb[j] = *at(p.panel.price, pb + (unsigned)min(i0 + j, N - 1));
+#pragma unroll
+        for (int j = 0; j < kPB; ++j) pin(prb[j]);
+#pragma unroll
+        for (int j = 0; j < kPB; ++j) {
+            const int i = i0 + j;
+            if (i >= N) break;
+            const float a = row[i];
+            const double pr = prb[j];
+            if (a > 0.0f && pr > 0.0) {
+                const double avail = cr_floordiv(cash, pr);                   // cash // price
+                const double buy = ((double)a < avail) ? (double)a : avail;   // min(avail, a)
+                const float s = stk[i * kWave + lane];
+                stk[i * kWave + lane] = (float)((double)s + buy);
+                cash -= pr * buy * one_p_cb;
+            }
         }
     }
     const bool done = time == max_step;                                       // :80

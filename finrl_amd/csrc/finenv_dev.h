@@ -35,4 +35,142 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Keep a just-loaded value in a register HERE.  hipcc sinks a load into the (conditional) block
+// that holds its only use, which turns "issue a batch of loads, then consume them" back into
+// load / s_waitcnt vmcnt(0) / use, one exposed HBM round trip per element.
+template <typename T>
+__device__ __forceinline__ void pin(T &x)
+{
+    asm volatile("" : "+v"(x));
+}
+
+// Transpose a [nenv_w][N] f32 action tile (row-major in HBM, what SB3 / ElegantRL hand over) into
+// LDS rows of `stride` dwords: rows[el * stride + i] = act[el][i].  kBatch coalesced loads are
+// issued before the first LDS write; a plain rolled loop (load, index math, ds_write) exposes one
+// HBM round trip per 64 floats at one wave per SIMD.  magicN = ceil(2^32 / N) (N >= 2).
+template <int kBatch = 32>
+__device__ __forceinline__ void stage_action_tile(float *rows, int stride,
+                                                  const float *__restrict__ src, int nenv_w, int N,
+                                                  unsigned magicN, int lane)
+{
+    const int total = nenv_w * N;
+    for (int f0 = 0; f0 < total; f0 += kBatch * kWaveSize) {
+        float v[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int f = f0 + j * kWaveSize + lane;
+            v[j] = *at(src, (unsigned)(f < total ? f : total - 1));
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) pin(v[j]);
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int f = f0 + j * kWaveSize + lane;
+            if (f < total) {
+                const int el = (N == 1) ? f : (int)__umulhi((unsigned)f, magicN);
+                rows[el * stride + (f - el * N)] = v[j];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Observation-row writer shared by the sibling env kernels (one wave, lane = column within a
+// 64-column chunk).  For each env el selected by lane_mask it writes D floats to dst[el * D ..]:
+//   column col comes from heads[el * head_stride + patch_sel(col)] when patch_sel(col) >= 0
+//   (per-env values published in LDS), else from tmpl[tmpl_index(day_el, col)] (market data;
+//   tmpl_index < 0 = no source, writes 0).
+// Memory-op order is what matters here (vmcnt is in-order on gfx950: a load placed between
+// stores waits until every older store is acknowledged):
+//   * all selected envs on the same panel row (lock-step batches): the template values of up to
+//     kMaxChunks chunks are loaded ONCE, then the env loop holds nothing but stores, in
+//     row-major order (neighbouring chunks of a row back to back: L2 merges the 64-B segments
+//     that a row of odd length straddles);
+//   * per-env rows (random starts): kBatch rows' loads are issued before the batch's stores.
+// ---------------------------------------------------------------------------------------------
+template <int kMaxChunks, int kBatch, typename TmplIndex, typename PatchSel>
+__device__ __forceinline__ void write_obs_rows_generic(float *__restrict__ dst,
+                                                       const float *__restrict__ tmpl, int D,
+                                                       int e0, int nenv_w, int row_day,
+                                                       unsigned long long lane_mask,
+                                                       const float *heads, int head_stride,
+                                                       int lane, TmplIndex tmpl_index,
+                                                       PatchSel patch_sel)
+{
+    if (lane_mask == 0ull) return;
+    const int first = __builtin_ctzll(lane_mask);
+    const int d0 = __builtin_amdgcn_readlane(row_day, first);
+    const bool mine = (lane_mask >> lane) & 1ull;
+    const bool uniform = __all(!mine || row_day == d0);
+    float *const base = dst + (size_t)e0 * D;
+    const int nchunk = (D + kWaveSize - 1) / kWaveSize;
+
+    if (uniform && nchunk <= kMaxChunks) {
+        float t[kMaxChunks];
+        int sel[kMaxChunks];
+#pragma unroll
+        for (int k = 0; k < kMaxChunks; ++k) {
+            const int col = k * kWaveSize + lane;
+            const bool in = k < nchunk && col < D;
+            sel[k] = in ? patch_sel(col) : -1;
+            const int idx = (in && sel[k] < 0) ? tmpl_index(d0, col) : -1;
+            t[k] = 0.0f;
+            if (tmpl != nullptr) {
+                const float x = *at(tmpl, (unsigned)(idx >= 0 ? idx : 0));
+                t[k] = idx >= 0 ? x : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kMaxChunks; ++k) pin(t[k]);
+        for (int el = 0; el < nenv_w; ++el) {
+            if (!((lane_mask >> el) & 1ull)) continue;
+#pragma unroll
+            for (int k = 0; k < kMaxChunks; ++k) {
+                if (k >= nchunk) break;
+                const int col = k * kWaveSize + lane;
+                float v = t[k];
+                if (__any(sel[k] >= 0)) {
+                    const float hv = heads[el * head_stride + (sel[k] >= 0 ? sel[k] : 0)];
+                    v = sel[k] >= 0 ? hv : v;
+                }
+                if (col < D) *at(base, (unsigned)(el * D + col)) = v;
+            }
+        }
+        return;
+    }
+
+    for (int k = 0; k < nchunk; ++k) {
+        const int col = k * kWaveSize + lane;
+        const bool in = col < D;
+        const int s = in ? patch_sel(col) : -1;
+        const bool any_patch = __any(s >= 0);
+        for (int g = 0; g < nenv_w; g += kBatch) {
+            float t[kBatch];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const int de = __builtin_amdgcn_readlane(row_day, min(g + j, nenv_w - 1));
+                const int idx = (in && s < 0) ? tmpl_index(de, col) : -1;
+                t[j] = 0.0f;
+                if (tmpl != nullptr) {
+                    const float x = *at(tmpl, (unsigned)(idx >= 0 ? idx : 0));
+                    t[j] = idx >= 0 ? x : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) pin(t[j]);
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const int el = g + j;
+                if (el >= nenv_w || !((lane_mask >> el) & 1ull)) continue;
+                float v = t[j];
+                if (any_patch) {
+                    const float hv = heads[el * head_stride + (s >= 0 ? s : 0)];
+                    v = s >= 0 ? hv : v;
+                }
+                if (in) *at(base, (unsigned)(el * D + col)) = v;
+            }
+        }
+    }
+}
+
 }  // namespace

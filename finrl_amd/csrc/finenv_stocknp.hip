@@ -105,37 +105,14 @@ __device__ __forceinline__ void np_write_rows(float *__restrict__ dst, const NpP
                                               unsigned long long lane_mask, const float *heads,
                                               int lane)
 {
-    if (lane_mask == 0ull) return;
     const int N = p.cfg.n_tickers, D = p.D;
-    const int first = __builtin_ctzll(lane_mask);
-    const int d0 = __builtin_amdgcn_readlane(row_day, first);
-    const bool mine = (lane_mask >> lane) & 1ull;
-    const bool uniform = __all(!mine || row_day == d0);
-    float *const base = dst + (size_t)e0 * D;
-    const int nchunk = (D + kWave - 1) / kWave;
-    for (int k = 0; k < nchunk; ++k) {
-        const int col = k * kWave + lane;
-        const bool in = col < D;
-        const int hidx = col - 3 - N;                        // stocks then cool_down
-        const bool patch = in && (col == 0 || (hidx >= 0 && hidx < 2 * N));
-        const int sel = (col == 0) ? 0 : (patch ? 1 + hidx : 0);
-        const bool any_patch = __any(patch);
-        float t = 0.0f;
-        if (uniform && in) t = *at(p.panel.obs_tmpl, (unsigned)(d0 * D + col));
-        for (int el = 0; el < nenv_w; ++el) {
-            if (!((lane_mask >> el) & 1ull)) continue;
-            float v = t;
-            if (!uniform) {
-                const int de = __builtin_amdgcn_readlane(row_day, el);
-                if (in) v = *at(p.panel.obs_tmpl, (unsigned)(de * D + col));
-            }
-            if (any_patch) {
-                const float hv = heads[el * kRowH + sel];
-                v = patch ? hv : v;
-            }
-            if (in) *at(base, (unsigned)(el * D + col)) = v;
-        }
-    }
+    write_obs_rows_generic<8, 16>(
+        dst, p.panel.obs_tmpl, D, e0, nenv_w, row_day, lane_mask, heads, kRowH, lane,
+        [=](int day, int col) { return day * D + col; },
+        [=](int col) {                                       // amount | ... | stocks | cool_down
+            const int hidx = col - 3 - N;
+            return col == 0 ? 0 : ((hidx >= 0 && hidx < 2 * N) ? 1 + hidx : -1);
+        });
 }
 
 // (stocks * price).sum() in float32, NumPy pairwise order (8 accumulators, n < 128)
@@ -224,14 +201,7 @@ __global__ void __launch_bounds__(kWave *kWaves) stocknp_kernel(const NpParams p
     }
 
     // ---- action tile -> LDS rows (stride kRowA inside the heads region) ---------------------
-    {
-        const float *__restrict__ src = p.actions + (size_t)e0 * N;
-        const int total = nenv_w * N;
-        for (int f = lane; f < total; f += kWave) {
-            const int el = (N == 1) ? f : (int)__umulhi((unsigned)f, p.magicN);
-            heads[el * kRowA + (f - el * N)] = *at(src, (unsigned)f);
-        }
-    }
+    stage_action_tile(heads, kRowA, p.actions + (size_t)e0 * N, nenv_w, N, p.magicN, lane);
     const int tags = NI(FINENV_NI_TAGS);
     Num amount = mk(NF(FINENV_NF_AMOUNT), tags & 3);
     const Num ta_old = mk(NF(FINENV_NF_TOTAL_ASSET), (tags >> 2) & 3);
@@ -239,9 +209,23 @@ __global__ void __launch_bounds__(kWave *kWaves) stocknp_kernel(const NpParams p
     Num ita = mk(NF(FINENV_NF_INITIAL_TOTAL_ASSET), (tags >> 6) & 3);
     const int day = NI(FINENV_NI_DAY) + 1;                                        // :106
     const unsigned pb = (unsigned)(day * N);
-    for (int i = 0; i < N; ++i) {
-        scol[i * kWave] = NS(0, i);
-        ccol[i * kWave] = NS(1, i) + 1.0f;                                        // :108
+    // (global loads in batches, issued before their first use: a rolled loop exposes one HBM round
+    //  trip per ticker at one wave per SIMD)
+    for (int i0 = 0; i0 < N; i0 += 16) {
+        float sv[16], cv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            sv[j] = NS(0, min(i0 + j, N - 1));
+            cv[j] = NS(1, min(i0 + j, N - 1));
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { pin(sv[j]); pin(cv[j]); }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (i0 + j >= N) break;
+            scol[(i0 + j) * kWave] = sv[j];
+            ccol[(i0 + j) * kWave] = cv[j] + 1.0f;                                // :108
+        }
     }
     wave_sync();
     const float *arow = heads + lane * kRowA;
@@ -252,9 +236,19 @@ __global__ void __launch_bounds__(kWave *kWaves) stocknp_kernel(const NpParams p
     const int min_action = p.cfg.min_action;
 
     // sells then buys, ticker index order (:112-129); liquidation when turbulent (:131-134)
-    for (int i = 0; i < N; ++i) {
+    constexpr int kPB = 8;                    // price loads per batch
+    for (int i0 = 0; i0 < N; i0 += kPB) {
+        float prb[kPB];
+#pragma unroll
+        for (int j = 0; j < kPB; ++j) prb[j] = *at(p.panel.price, pb + (unsigned)min(i0 + j, N - 1));
+#pragma unroll
+        for (int j = 0; j < kPB; ++j) pin(prb[j]);
+#pragma unroll
+        for (int j = 0; j < kPB; ++j) {
+        const int i = i0 + j;
+        if (i >= N) break;
         const int a = (int)(arow[i] * ms);                                        // :104
-        const float pr = *at(p.panel.price, pb + (unsigned)i);
+        const float pr = prb[j];
         if (calm && a < -min_action && pr > 0.0f) {
             const float s = scol[i * kWave];
             const double want = (double)(-a);
@@ -267,10 +261,20 @@ __global__ void __launch_bounds__(kWave *kWaves) stocknp_kernel(const NpParams p
             amount = n_add(amount, n_mul(t0, one_m));
             ccol[i * kWave] = 0.0f;
         }
+        }
     }
-    for (int i = 0; i < N; ++i) {
+    for (int i0 = 0; i0 < N; i0 += kPB) {
+        float prb[kPB];
+#pragma unroll
+        for (int j = 0; j < kPB; ++j) prb[j] = *at(p.panel.price, pb + (unsigned)min(i0 + j, N - 1));
+#pragma unroll
+        for (int j = 0; j < kPB; ++j) pin(prb[j]);
+#pragma unroll
+        for (int j = 0; j < kPB; ++j) {
+        const int i = i0 + j;
+        if (i >= N) break;
         const int a = (int)(arow[i] * ms);
-        const float pr = *at(p.panel.price, pb + (unsigned)i);
+        const float pr = prb[j];
         if (calm && a > min_action && pr > 0.0f) {
             const Num q = n_floordiv(amount, mk((double)pr, FINENV_NT_F32));      // amount // price
             const bool is_int = (double)a < q.v;             // min(q, a) -> a (np.int64)
@@ -281,6 +285,7 @@ __global__ void __launch_bounds__(kWave *kWaves) stocknp_kernel(const NpParams p
             scol[i * kWave] = (float)((double)s + buy);
             amount = n_sub(amount, n_mul(t0, one_p));
             ccol[i * kWave] = 0.0f;
+        }
         }
     }
     if (!calm) {
