@@ -78,6 +78,41 @@ def cpu_baseline(close, tech, risk, budget_s=12.0):
                        f"(host has {os.cpu_count()} cores)")
 
 
+def cpu_baseline_threads(close, tech, risk, n_threads, budget_s=6.0):
+    """Same oracle, one independent env shard per thread (ctypes releases the GIL inside the C
+    call): what the host cores this process may use deliver together.  Reported beside
+    `cpu_baseline` (which stays the single-thread figure), never a target."""
+    import threading
+    from oracle.stock import StockOracle
+    Ec, chunk = 256, 100
+    rng = np.random.default_rng(4321)
+    acts = rng.uniform(-1, 1, (8, Ec, close.shape[1])).astype(np.float32)
+    orcs = [StockOracle(close, tech, risk, n_envs=Ec, **ENV_KW) for _ in range(n_threads)]
+    for o in orcs:
+        o.reset()
+        o.vec_step(acts[0])
+    counts = [0] * n_threads
+    stop = time.perf_counter() + budget_s
+
+    def work(k):
+        o = orcs[k]
+        while time.perf_counter() < stop:
+            for j in range(chunk):
+                o.vec_step(acts[j & 7])
+            counts[k] += chunk
+
+    t0 = time.perf_counter()
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(n_threads)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    return dict(value=Ec * sum(counts) / dt, unit="env-steps/s", cores=n_threads, kind="port",
+                sample=f"{n_threads} threads x {Ec} envs, {sum(counts)} steps in total ({dt:.1f} s), "
+                       "same workload and oracle as cpu_baseline")
+
+
 def bench_portfolio(args, torch, dev):
     """BASELINE.json configs[2]: 65,536 vectorised StockPortfolioEnv, DOW30, K=8 (side metric;
     the driver's default line is the stock env)."""
@@ -306,6 +341,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(close, tech, risk)
+            nthr = max(1, min(16, len(os.sched_getaffinity(0))))    # the box's CPU share for one GPU
+            if nthr > 1:
+                out["cpu_baseline_all_cores"] = cpu_baseline_threads(close, tech, risk, nthr)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
