@@ -95,23 +95,26 @@ __device__ __forceinline__ void write_obs_rows_generic(float *__restrict__ dst,
                                                        unsigned long long lane_mask,
                                                        const float *heads, int head_stride,
                                                        int lane, TmplIndex tmpl_index,
-                                                       PatchSel patch_sel)
+                                                       PatchSel patch_sel, int k_lo = 0,
+                                                       int k_hi = 1 << 30)
 {
+    // [k_lo, k_hi): chunk range to write (a streamer wave takes the pure market-data chunks)
     if (lane_mask == 0ull) return;
     const int first = __builtin_ctzll(lane_mask);
     const int d0 = __builtin_amdgcn_readlane(row_day, first);
     const bool mine = (lane_mask >> lane) & 1ull;
     const bool uniform = __all(!mine || row_day == d0);
     float *const base = dst + (size_t)e0 * D;
-    const int nchunk = (D + kWaveSize - 1) / kWaveSize;
+    const int nchunk = min(k_hi, (D + kWaveSize - 1) / kWaveSize);
+    if (k_lo >= nchunk) return;
 
-    if (uniform && nchunk <= kMaxChunks) {
+    if (uniform && nchunk - k_lo <= kMaxChunks) {
         float t[kMaxChunks];
         int sel[kMaxChunks];
 #pragma unroll
         for (int k = 0; k < kMaxChunks; ++k) {
-            const int col = k * kWaveSize + lane;
-            const bool in = k < nchunk && col < D;
+            const int col = (k_lo + k) * kWaveSize + lane;
+            const bool in = k_lo + k < nchunk && col < D;
             sel[k] = in ? patch_sel(col) : -1;
             const int idx = (in && sel[k] < 0) ? tmpl_index(d0, col) : -1;
             t[k] = 0.0f;
@@ -126,8 +129,8 @@ __device__ __forceinline__ void write_obs_rows_generic(float *__restrict__ dst,
             if (!((lane_mask >> el) & 1ull)) continue;
 #pragma unroll
             for (int k = 0; k < kMaxChunks; ++k) {
-                if (k >= nchunk) break;
-                const int col = k * kWaveSize + lane;
+                if (k_lo + k >= nchunk) break;
+                const int col = (k_lo + k) * kWaveSize + lane;
                 float v = t[k];
                 if (__any(sel[k] >= 0)) {
                     const float hv = heads[el * head_stride + (sel[k] >= 0 ? sel[k] : 0)];
@@ -139,7 +142,7 @@ __device__ __forceinline__ void write_obs_rows_generic(float *__restrict__ dst,
         return;
     }
 
-    for (int k = 0; k < nchunk; ++k) {
+    for (int k = k_lo; k < nchunk; ++k) {
         const int col = k * kWaveSize + lane;
         const bool in = col < D;
         const int s = in ? patch_sel(col) : -1;

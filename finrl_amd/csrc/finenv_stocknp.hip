@@ -103,7 +103,7 @@ __device__ __forceinline__ Num n_floordiv(Num a, Num b)      // b > 0
 __device__ __forceinline__ void np_write_rows(float *__restrict__ dst, const NpParams &p, int e0,
                                               int nenv_w, int row_day,
                                               unsigned long long lane_mask, const float *heads,
-                                              int lane)
+                                              int lane, int k_lo = 0, int k_hi = 1 << 30)
 {
     const int N = p.cfg.n_tickers, D = p.D;
     write_obs_rows_generic<8, 16>(
@@ -112,7 +112,7 @@ __device__ __forceinline__ void np_write_rows(float *__restrict__ dst, const NpP
         [=](int col) {                                       // amount | ... | stocks | cool_down
             const int hidx = col - 3 - N;
             return col == 0 ? 0 : ((hidx >= 0 && hidx < 2 * N) ? 1 + hidx : -1);
-        });
+        }, k_lo, k_hi);
 }
 
 // (stocks * price).sum() in float32, NumPy pairwise order (8 accumulators, n < 128)
@@ -139,12 +139,17 @@ __device__ __forceinline__ float holdings_value(const float *scol, const float *
     return sum;
 }
 
+// step launches carry a second set of kWaves "streamer" waves per block (role 1): done and the
+// panel row of the next observation depend only on the day counter (:106, :137), so the chunks
+// of the observation rows that hold no per-env value (4 of 6 at DOW30x8) are streamed from the
+// first microsecond on, beside the trade arithmetic, instead of after it.
 template <bool RESET_ONLY>
-__global__ void __launch_bounds__(kWave *kWaves) stocknp_kernel(const NpParams p)
+__global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_kernel(const NpParams p)
 {
     __shared__ float lds_all[kWaves * kLdsPerWave];
     const int lane = threadIdx.x & (kWave - 1);
-    const int wib = threadIdx.x >> 6;
+    const int wib = (threadIdx.x >> 6) % kWaves;
+    const int role = (threadIdx.x >> 6) / kWaves;          // 0 trader, 1 streamer (step only)
     float *heads = lds_all + wib * kLdsPerWave;            // [env][kRowH] (actions use stride kRowA)
     float *stk = heads + kWave * kRowH;                    // [ticker][lane]
     float *cdl = stk + kMaxN * kWave;                      // [ticker][lane]
@@ -200,7 +205,23 @@ __global__ void __launch_bounds__(kWave *kWaves) stocknp_kernel(const NpParams p
         return;
     }
 
+    const int kpatch = (2 + 3 * N) / kWave + 1;            // chunks that hold amount / stocks / cool_down
+    if (role == 1) {
+        int day_s = NI(FINENV_NI_DAY) + 1;
+        // the day counter is read (and has arrived) before the block-wide barrier; the traders
+        // overwrite it only at the very end, long after they passed the same barrier
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(day_s) : : "memory");
+        lds_barrier();
+        const bool done_s = day_s == p.cfg.n_days - 1;
+        const unsigned long long vm = __ballot(valid), dm = __ballot(done_s && valid);
+        if (dm != 0ull && p.term_obs != nullptr)
+            np_write_rows(p.term_obs, p, e0, nenv_w, day_s, dm, heads, lane, kpatch);
+        const int rd = (done_s && p.auto_reset) ? 0 : day_s;
+        np_write_rows(p.obs, p, e0, nenv_w, rd, vm, heads, lane, kpatch);
+        return;
+    }
     // ---- action tile -> LDS rows (stride kRowA inside the heads region) ---------------------
+    lds_barrier();                           // pairs with the streamers' barrier (see above)
     stage_action_tile(heads, kRowA, p.actions + (size_t)e0 * N, nenv_w, N, p.magicN, lane);
     const int tags = NI(FINENV_NI_TAGS);
     Num amount = mk(NF(FINENV_NF_AMOUNT), tags & 3);
@@ -318,7 +339,7 @@ __global__ void __launch_bounds__(kWave *kWaves) stocknp_kernel(const NpParams p
     int row_day = day;
     if (done_mask != 0ull) {
         if (p.term_obs != nullptr)
-            np_write_rows(p.term_obs, p, e0, nenv_w, day, done_mask, heads, lane);
+            np_write_rows(p.term_obs, p, e0, nenv_w, day, done_mask, heads, lane, 0, kpatch);
         if (p.auto_reset) {
             wave_sync();
             if (done) {
@@ -329,7 +350,7 @@ __global__ void __launch_bounds__(kWave *kWaves) stocknp_kernel(const NpParams p
             wave_sync();
         }
     }
-    np_write_rows(p.obs, p, e0, nenv_w, row_day, valid_mask, heads, lane);
+    np_write_rows(p.obs, p, e0, nenv_w, row_day, valid_mask, heads, lane, 0, kpatch);
     if (valid) store_state(amount, ta, gr, ita, r.tag, row_day);
 }
 
@@ -445,7 +466,7 @@ int finenv_stocknp_step(finenv_stocknp *h, const float *actions, float *obs, flo
     p.done = done;
     p.term_obs = term_obs;
     p.auto_reset = auto_reset;
-    hipLaunchKernelGGL((stocknp_kernel<false>), np_grid(h->cfg.n_envs), dim3(kWave * kWaves), 0,
+    hipLaunchKernelGGL((stocknp_kernel<false>), np_grid(h->cfg.n_envs), dim3(kWave * kWaves * 2), 0,
                        (hipStream_t)stream, p);
     return np_check(h, "stocknp_step");
 }
