@@ -88,7 +88,10 @@ __device__ __forceinline__ void stage_action_tile(float *rows, int stride,
 //     that a row of odd length straddles);
 //   * per-env rows (random starts): kBatch rows' loads are issued before the batch's stores.
 // ---------------------------------------------------------------------------------------------
-template <int kMaxChunks, int kBatch, typename TmplIndex, typename PatchSel>
+//   * kCompact: plain rolled loops (small code) for paths that run once per episode -- the env
+//     kernels must stay inside the 64 KB instruction cache two CUs share: at 79 KB the
+//     cash-penalty step kernel ran 2x slower than at 57 KB with strictly less work per wave.
+template <int kMaxChunks, int kBatch, bool kCompact = false, typename TmplIndex, typename PatchSel>
 __device__ __forceinline__ void write_obs_rows_generic(float *__restrict__ dst,
                                                        const float *__restrict__ tmpl, int D,
                                                        int e0, int nenv_w, int row_day,
@@ -107,6 +110,24 @@ __device__ __forceinline__ void write_obs_rows_generic(float *__restrict__ dst,
     float *const base = dst + (size_t)e0 * D;
     const int nchunk = min(k_hi, (D + kWaveSize - 1) / kWaveSize);
     if (k_lo >= nchunk) return;
+
+    if constexpr (kCompact) {
+        for (int k = k_lo; k < nchunk; ++k) {
+            const int col = k * kWaveSize + lane;
+            const bool in = col < D;
+            const int s = in ? patch_sel(col) : -1;
+            for (int el = 0; el < nenv_w; ++el) {
+                if (!((lane_mask >> el) & 1ull)) continue;
+                const int de = __builtin_amdgcn_readlane(row_day, el);
+                const int idx = (in && s < 0) ? tmpl_index(de, col) : -1;
+                float v = 0.0f;
+                if (tmpl != nullptr && idx >= 0) v = *at(tmpl, (unsigned)idx);
+                if (s >= 0) v = heads[el * head_stride + s];
+                if (in) *at(base, (unsigned)(el * D + col)) = v;
+            }
+        }
+        return;
+    }
 
     if (uniform && nchunk - k_lo <= kMaxChunks) {
         float t[kMaxChunks];

@@ -100,13 +100,14 @@ __device__ __forceinline__ Num n_floordiv(Num a, Num b)      // b > 0
 }
 
 // heads[el*kRowH + 0] = amount*2^-12 (f32), [1..N] stocks*2^-6, [1+N..2N] cool_down
+template <bool kCompact = false>
 __device__ __forceinline__ void np_write_rows(float *__restrict__ dst, const NpParams &p, int e0,
                                               int nenv_w, int row_day,
                                               unsigned long long lane_mask, const float *heads,
                                               int lane, int k_lo = 0, int k_hi = 1 << 30)
 {
     const int N = p.cfg.n_tickers, D = p.D;
-    write_obs_rows_generic<8, 16>(
+    write_obs_rows_generic<8, 16, kCompact>(
         dst, p.panel.obs_tmpl, D, e0, nenv_w, row_day, lane_mask, heads, kRowH, lane,
         [=](int day, int col) { return day * D + col; },
         [=](int col) {                                       // amount | ... | stocks | cool_down
@@ -215,7 +216,7 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
         const bool done_s = day_s == p.cfg.n_days - 1;
         const unsigned long long vm = __ballot(valid), dm = __ballot(done_s && valid);
         if (dm != 0ull && p.term_obs != nullptr)
-            np_write_rows(p.term_obs, p, e0, nenv_w, day_s, dm, heads, lane, kpatch);
+            np_write_rows<true>(p.term_obs, p, e0, nenv_w, day_s, dm, heads, lane, kpatch);
         const int rd = (done_s && p.auto_reset) ? 0 : day_s;
         np_write_rows(p.obs, p, e0, nenv_w, rd, vm, heads, lane, kpatch);
         return;
@@ -339,7 +340,7 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
     int row_day = day;
     if (done_mask != 0ull) {
         if (p.term_obs != nullptr)
-            np_write_rows(p.term_obs, p, e0, nenv_w, day, done_mask, heads, lane, 0, kpatch);
+            np_write_rows<true>(p.term_obs, p, e0, nenv_w, day, done_mask, heads, lane, 0, kpatch);
         if (p.auto_reset) {
             wave_sync();
             if (done) {

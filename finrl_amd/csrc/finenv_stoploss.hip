@@ -76,13 +76,14 @@ __device__ __forceinline__ double sl_reward(const finenv_stoploss_config &c, int
 }
 
 // rows[el*kRow + 0] = f32 cash, rows[el*kRow + 1 + i] = f32 holdings_i; columns > N: info row
+template <bool kCompact = false>
 __device__ __forceinline__ void sl_write_rows(float *__restrict__ dst, const SlParams &p, int e0,
                                               int nenv_w, int row_day,
                                               unsigned long long lane_mask, const float *rows,
                                               int lane)
 {
     const int N = p.cfg.n_assets, D = p.D, W = D - 1 - N;
-    write_obs_rows_generic<8, 32>(
+    write_obs_rows_generic<8, 32, kCompact>(
         dst, W > 0 ? p.panel.info : nullptr, D, e0, nenv_w, row_day, lane_mask, rows, kRow, lane,
         [=](int day, int col) { return day * W + col - 1 - N; },
         [=](int col) { return col <= N ? col : -1; });
@@ -351,7 +352,7 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
     int row_day = di;
     if (done_mask != 0ull) {
         if (p.term_obs != nullptr)
-            sl_write_rows(p.term_obs, p, e0, nenv_w, di, done_mask, rows, lane);
+            sl_write_rows<true>(p.term_obs, p, e0, nenv_w, di, done_mask, rows, lane);   // once per episode
         if (p.auto_reset) {                                                      // reset()
             wave_sync();
             if (done) {
