@@ -273,3 +273,48 @@ class SB3VecEnvAdapter:
     def env_method(self, name, *args, indices=None, **kwargs):
         r = getattr(self.env, name)(*args, **kwargs)
         return [r] * self.num_envs
+
+
+class SingleEnvVecAdapter:
+    """``DummyVecEnv([lambda: env])``-shaped wrapper around one of the single-env facades
+    (what the reference's ``get_sb_env`` returns): numpy in / out, auto-reset with
+    ``infos[0]["terminal_observation"]``."""
+
+    def __init__(self, env):
+        self.env = env
+        self.envs = [env]
+        self.num_envs = 1
+        self.observation_space = env.observation_space
+        self.action_space = env.action_space
+        self._actions = None
+
+    def reset(self):
+        return np.asarray(self.env.reset())[None]
+
+    def step_async(self, actions):
+        self._actions = np.asarray(actions)
+
+    def step_wait(self):
+        obs, rew, done, info = self.env.step(self._actions[0])
+        info = dict(info) if isinstance(info, dict) else {}
+        if done:
+            info["terminal_observation"] = np.asarray(obs)
+            obs = self.env.reset()
+        return (np.asarray(obs)[None], np.asarray([rew], dtype=np.float32),
+                np.asarray([done]), [info])
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def env_method(self, name, *a, **k):
+        return [getattr(self.env, name)(*a, **k)]
+
+    def get_attr(self, name, indices=None):
+        return [getattr(self.env, name)]
+
+    def set_attr(self, name, value, indices=None):
+        setattr(self.env, name, value)
+
+    def close(self):
+        pass

@@ -107,11 +107,11 @@ class VecStockTradingEnvNP:
         import torch
         E, N = self.num_envs, self.action_dim
         s = np.broadcast_to(np.asarray(stocks0, np.float32), (E, N))
-        self.state["stocks0"].copy_(torch.from_numpy(np.ascontiguousarray(s.T)))
+        self.state["stocks0"].copy_(torch.from_numpy(np.array(s.T, order="C", copy=True)))
         self.state["amount0"].copy_(torch.from_numpy(
-            np.ascontiguousarray(np.broadcast_to(np.asarray(amount0, np.float64), (E,)))))
+            np.array(np.broadcast_to(np.asarray(amount0, np.float64), (E,)), copy=True)))
         self.state["amount0_tag"].copy_(torch.from_numpy(
-            np.ascontiguousarray(np.broadcast_to(np.asarray(amount0_tag, np.int32), (E,)))))
+            np.array(np.broadcast_to(np.asarray(amount0_tag, np.int32), (E,)), copy=True)))
 
     def _draw_train_start(self):
         """Train-mode start state (:85-92), drawn on device with this env's generator (the
