@@ -15,6 +15,7 @@
 
 #include "finenv.h"
 #include "finenv_dev.h"
+#include "finenv_host.h"
 
 namespace {
 
@@ -324,6 +325,7 @@ __global__ void __launch_bounds__(kWave *kWaves) cashpenalty_kernel(const CpPara
 }  // namespace
 
 struct finenv_cashpenalty {
+    int device;           // HIP device that owns the bound state block (-1 before bind)
     finenv_cashpenalty_config cfg;
     finenv_cashpenalty_panel panel;
     finenv_cashpenalty_state st;
@@ -384,6 +386,7 @@ int finenv_cashpenalty_create(const finenv_cashpenalty_config *cfg, finenv_cashp
     finenv_cashpenalty *h = new (std::nothrow) finenv_cashpenalty;
     if (!h) return FINENV_ERR_NOMEM;
     memset(h, 0, sizeof(*h));
+    h->device = -1;
     h->cfg = *cfg;
     h->D = (int)D;
     h->magicN = N >= 2 ? (uint32_t)(((1ull << 32) + N - 1) / (unsigned long long)N) : 0u;
@@ -407,6 +410,7 @@ int finenv_cashpenalty_bind(finenv_cashpenalty *h, const finenv_cashpenalty_pane
         return kp_fail(h, FINENV_ERR_INVALID, "bind: null pointer");
     h->panel = *panel;
     h->st = *st;
+    h->device = finenv_host::pointer_device(st->f64);
     h->bound = 1;
     return FINENV_OK;
 }
@@ -416,6 +420,7 @@ int finenv_cashpenalty_reset(finenv_cashpenalty *h, const uint8_t *mask, float *
 {
     if (!h) return FINENV_ERR_INVALID;
     if (!h->bound) return kp_fail(h, FINENV_ERR_UNBOUND, "reset: bind first");
+    const finenv_host::DeviceGuard guard(h->device);
     CpParams p = kp_params(h);
     p.mask = mask;
     p.obs = obs_out;
@@ -430,6 +435,7 @@ int finenv_cashpenalty_step(finenv_cashpenalty *h, const float *actions, float *
 {
     if (!h) return FINENV_ERR_INVALID;
     if (!h->bound) return kp_fail(h, FINENV_ERR_UNBOUND, "step: bind first");
+    const finenv_host::DeviceGuard guard(h->device);
     if (!actions || !obs || !reward || !done)
         return kp_fail(h, FINENV_ERR_INVALID, "step: null actions/obs/reward/done");
     CpParams p = kp_params(h);

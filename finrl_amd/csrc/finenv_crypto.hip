@@ -18,6 +18,7 @@
 
 #include "finenv.h"
 #include "finenv_dev.h"
+#include "finenv_host.h"
 
 namespace {
 
@@ -257,6 +258,7 @@ __global__ void __launch_bounds__(kWave *kWaves) crypto_kernel(const CrParams p)
 }  // namespace
 
 struct finenv_crypto {
+    int device;           // HIP device that owns the bound state block (-1 before bind)
     finenv_crypto_config cfg;
     finenv_crypto_panel panel;
     finenv_crypto_state st;
@@ -321,6 +323,7 @@ int finenv_crypto_create(const finenv_crypto_config *cfg, finenv_crypto **out)
     finenv_crypto *h = new (std::nothrow) finenv_crypto;
     if (!h) return FINENV_ERR_NOMEM;
     memset(h, 0, sizeof(*h));
+    h->device = -1;
     h->cfg = *cfg;
     h->D = (int)D;
     h->magicN = magic_for(N);
@@ -342,6 +345,7 @@ int finenv_crypto_bind(finenv_crypto *h, const finenv_crypto_panel *panel,
         return cr_fail(h, FINENV_ERR_INVALID, "bind: null pointer");
     h->panel = *panel;
     h->st = *st;
+    h->device = finenv_host::pointer_device(st->f64);
     h->bound = 1;
     return FINENV_OK;
 }
@@ -350,6 +354,7 @@ int finenv_crypto_reset(finenv_crypto *h, const uint8_t *mask, float *obs_out, v
 {
     if (!h) return FINENV_ERR_INVALID;
     if (!h->bound) return cr_fail(h, FINENV_ERR_UNBOUND, "reset: bind first");
+    const finenv_host::DeviceGuard guard(h->device);
     CrParams p = cr_params(h);
     p.mask = mask;
     p.obs = obs_out;
@@ -363,6 +368,7 @@ int finenv_crypto_step(finenv_crypto *h, const float *actions, float *obs, float
 {
     if (!h) return FINENV_ERR_INVALID;
     if (!h->bound) return cr_fail(h, FINENV_ERR_UNBOUND, "step: bind first");
+    const finenv_host::DeviceGuard guard(h->device);
     if (!actions || !obs || !reward || !done)
         return cr_fail(h, FINENV_ERR_INVALID, "step: null actions/obs/reward/done");
     CrParams p = cr_params(h);

@@ -22,6 +22,7 @@
 
 #include "finenv.h"
 #include "finenv_dev.h"
+#include "finenv_host.h"
 
 namespace {
 
@@ -234,6 +235,7 @@ __global__ void __launch_bounds__(kThreads) portfolio_reset_kernel(const PfParam
 }  // namespace
 
 struct finenv_portfolio {
+    int device;           // HIP device that owns the bound state block (-1 before bind)
     finenv_portfolio_config cfg;
     finenv_portfolio_panel panel;
     finenv_portfolio_state st;
@@ -288,6 +290,7 @@ int finenv_portfolio_create(const finenv_portfolio_config *cfg, finenv_portfolio
     finenv_portfolio *h = new (std::nothrow) finenv_portfolio;
     if (!h) return FINENV_ERR_NOMEM;
     memset(h, 0, sizeof(*h));
+    h->device = -1;
     h->cfg = *cfg;
     h->D = (int)D;
     h->magicN = N >= 2 ? (uint32_t)(((1ull << 32) + N - 1) / (unsigned long long)N) : 0u;
@@ -307,6 +310,7 @@ int finenv_portfolio_bind(finenv_portfolio *h, const finenv_portfolio_panel *pan
         return pf_fail(h, FINENV_ERR_INVALID, "bind: null pointer");
     h->panel = *panel;
     h->st = *st;
+    h->device = finenv_host::pointer_device(st->f64);
     h->bound = 1;
     return FINENV_OK;
 }
@@ -315,6 +319,7 @@ int finenv_portfolio_reset(finenv_portfolio *h, const uint8_t *mask, float *obs_
 {
     if (!h) return FINENV_ERR_INVALID;
     if (!h->bound) return pf_fail(h, FINENV_ERR_UNBOUND, "reset: bind first");
+    const finenv_host::DeviceGuard guard(h->device);
     PfParams p = pf_params(h);
     p.mask = mask;
     p.obs = obs_out;
@@ -329,6 +334,7 @@ int finenv_portfolio_step(finenv_portfolio *h, const float *actions, float *obs,
 {
     if (!h) return FINENV_ERR_INVALID;
     if (!h->bound) return pf_fail(h, FINENV_ERR_UNBOUND, "step: bind first");
+    const finenv_host::DeviceGuard guard(h->device);
     if (!actions || !obs || !reward || !done)
         return pf_fail(h, FINENV_ERR_INVALID, "step: null actions/obs/reward/done");
     PfParams p = pf_params(h);

@@ -17,6 +17,7 @@
 
 #include "finenv.h"
 #include "finenv_dev.h"
+#include "finenv_host.h"
 
 namespace {
 
@@ -211,6 +212,7 @@ int finenv_riskpre_returns(const double *close, double *returns, int32_t n_days,
                            void *stream)
 {
     if (!close || !returns || n_days < 1 || n_assets < 1) return FINENV_ERR_INVALID;
+    const finenv_host::DeviceGuard guard(finenv_host::pointer_device(close));
     const long long total = (long long)n_days * n_assets;
     const unsigned blocks = (unsigned)((total + kThreads - 1) / kThreads > 4096
                                            ? 4096 : (total + kThreads - 1) / kThreads);
@@ -225,6 +227,7 @@ int finenv_riskpre_turbulence(const double *returns, double *quad, double *turbu
     if (!returns || !quad || !turbulence || n_assets < 2 ||
         n_assets > FINENV_RISKPRE_MAX_ASSETS || window < 3 || n_days < window)
         return FINENV_ERR_INVALID;
+    const finenv_host::DeviceGuard guard(finenv_host::pointer_device(returns));
     if (n_days > window) {
         RiskParams p = {returns, nullptr, quad, n_days, n_assets, window, 0, window};
         const int rc = launch_rolling<true>(p, n_days - window, (hipStream_t)stream);
@@ -241,6 +244,7 @@ int finenv_riskpre_rolling_cov(const double *returns, double *cov_out, int32_t n
     if (!returns || !cov_out || n_assets < 1 || n_assets > FINENV_RISKPRE_MAX_ASSETS ||
         lookback < 2 || n_days <= lookback)
         return FINENV_ERR_INVALID;
+    const finenv_host::DeviceGuard guard(finenv_host::pointer_device(returns));
     RiskParams p = {returns, cov_out, nullptr, n_days, n_assets, lookback, 1, lookback};
     return launch_rolling<false>(p, n_days - lookback, (hipStream_t)stream);
 }

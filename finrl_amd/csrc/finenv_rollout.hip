@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "finenv.h"
+#include "finenv_host.h"
 #include "finenv_dev.h"
 
 namespace {
@@ -44,6 +45,7 @@ extern "C" int finenv_gae_scan(const float *rewards, const float *values, const 
     if (!rewards || !values || !dones || !last_values || !advantages || !returns ||
         n_steps < 1 || n_envs < 1)
         return FINENV_ERR_INVALID;
+    const finenv_host::DeviceGuard guard(finenv_host::pointer_device(rewards));
     hipLaunchKernelGGL(gae_scan_kernel, dim3((n_envs + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream, rewards, values, dones, last_values, advantages,
                        returns, n_steps, n_envs, gamma, gae_lambda);

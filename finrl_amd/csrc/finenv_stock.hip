@@ -32,6 +32,7 @@
 
 #include "finenv.h"
 #include "finenv_dev.h"
+#include "finenv_host.h"
 
 namespace {
 
@@ -145,6 +146,7 @@ __global__ void stock_stats_kernel(const Params p)
 // Host side: handle, validation, launches.  No allocation on the device, no sync.
 // =====================================================================================
 struct finenv_stock {
+    int device;           // HIP device that owns the bound state block (-1 before bind)
     finenv_stock_config cfg;
     finenv_stock_panel panel;
     finenv_stock_state st;
@@ -306,6 +308,7 @@ int finenv_stock_create(const finenv_stock_config *cfg, finenv_stock **out)
     finenv_stock *h = new (std::nothrow) finenv_stock;
     if (!h) return FINENV_ERR_NOMEM;
     memset(h, 0, sizeof(*h));
+    h->device = -1;
     h->cfg = *cfg;
     h->D = 1 + 2 * cfg->n_tickers + cfg->n_tech * cfg->n_tickers;
     h->magicN = cfg->n_tickers >= 2
@@ -332,6 +335,7 @@ int finenv_stock_bind(finenv_stock *h, const finenv_stock_panel *panel,
         return fail(h, FINENV_ERR_INVALID, "bind: null state pointer%s");
     h->panel = *panel;
     h->st = *st;
+    h->device = finenv_host::pointer_device(st->f64);
     h->bound = 1;
     return FINENV_OK;
 }
@@ -340,6 +344,7 @@ int finenv_stock_init(finenv_stock *h, int32_t day0, void *stream)
 {
     if (!h) return FINENV_ERR_INVALID;
     if (!h->bound) return fail(h, FINENV_ERR_UNBOUND, "init: bind first%s");
+    const finenv_host::DeviceGuard guard(h->device);
     if (day0 < 0 || day0 >= h->cfg.n_days) return fail(h, FINENV_ERR_INVALID, "init: bad day0%s");
     Params p = make_params(h);
     p.day0 = day0;
@@ -351,6 +356,7 @@ int finenv_stock_reset(finenv_stock *h, const uint8_t *mask, float *obs_out, voi
 {
     if (!h) return FINENV_ERR_INVALID;
     if (!h->bound) return fail(h, FINENV_ERR_UNBOUND, "reset: bind first%s");
+    const finenv_host::DeviceGuard guard(h->device);
     Params p = make_params(h);
     p.mask = mask;
     p.obs = obs_out;
@@ -362,6 +368,7 @@ int finenv_stock_observe(finenv_stock *h, float *obs_out, void *stream)
 {
     if (!h || !obs_out) return FINENV_ERR_INVALID;
     if (!h->bound) return fail(h, FINENV_ERR_UNBOUND, "observe: bind first%s");
+    const finenv_host::DeviceGuard guard(h->device);
     Params p = make_params(h);
     p.obs = obs_out;
     launch_aux(h, p, 2, (hipStream_t)stream);
@@ -374,6 +381,7 @@ int finenv_stock_step(finenv_stock *h, const float *actions, float *obs, float *
 {
     if (!h) return FINENV_ERR_INVALID;
     if (!h->bound) return fail(h, FINENV_ERR_UNBOUND, "step: bind first%s");
+    const finenv_host::DeviceGuard guard(h->device);
     if (!actions || !obs || !reward || !done)
         return fail(h, FINENV_ERR_INVALID, "step: null actions/obs/reward/done%s");
     Params p = make_params(h);
@@ -406,6 +414,7 @@ int finenv_stock_episode_stats(finenv_stock *h, double *out, void *stream)
 {
     if (!h || !out) return FINENV_ERR_INVALID;
     if (!h->bound) return fail(h, FINENV_ERR_UNBOUND, "episode_stats: bind first%s");
+    const finenv_host::DeviceGuard guard(h->device);
     Params p = make_params(h);
     p.stats_out = out;
     const int E = h->cfg.n_envs;

@@ -17,6 +17,7 @@
 
 #include "finenv.h"
 #include "finenv_dev.h"
+#include "finenv_host.h"
 
 namespace {
 
@@ -358,6 +359,7 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
 }  // namespace
 
 struct finenv_stocknp {
+    int device;           // HIP device that owns the bound state block (-1 before bind)
     finenv_stocknp_config cfg;
     finenv_stocknp_panel panel;
     finenv_stocknp_state st;
@@ -418,6 +420,7 @@ int finenv_stocknp_create(const finenv_stocknp_config *cfg, finenv_stocknp **out
     finenv_stocknp *h = new (std::nothrow) finenv_stocknp;
     if (!h) return FINENV_ERR_NOMEM;
     memset(h, 0, sizeof(*h));
+    h->device = -1;
     h->cfg = *cfg;
     h->D = (int)D;
     h->magicN = N >= 2 ? (uint32_t)(((1ull << 32) + N - 1) / (unsigned long long)N) : 0u;
@@ -437,6 +440,7 @@ int finenv_stocknp_bind(finenv_stocknp *h, const finenv_stocknp_panel *panel,
         return np_fail(h, FINENV_ERR_INVALID, "bind: null pointer");
     h->panel = *panel;
     h->st = *st;
+    h->device = finenv_host::pointer_device(st->f64);
     h->bound = 1;
     return FINENV_OK;
 }
@@ -445,6 +449,7 @@ int finenv_stocknp_reset(finenv_stocknp *h, const uint8_t *mask, float *obs_out,
 {
     if (!h) return FINENV_ERR_INVALID;
     if (!h->bound) return np_fail(h, FINENV_ERR_UNBOUND, "reset: bind first");
+    const finenv_host::DeviceGuard guard(h->device);
     NpParams p = np_params(h);
     p.mask = mask;
     p.obs = obs_out;
@@ -458,6 +463,7 @@ int finenv_stocknp_step(finenv_stocknp *h, const float *actions, float *obs, flo
 {
     if (!h) return FINENV_ERR_INVALID;
     if (!h->bound) return np_fail(h, FINENV_ERR_UNBOUND, "step: bind first");
+    const finenv_host::DeviceGuard guard(h->device);
     if (!actions || !obs || !reward || !done)
         return np_fail(h, FINENV_ERR_INVALID, "step: null actions/obs/reward/done");
     NpParams p = np_params(h);

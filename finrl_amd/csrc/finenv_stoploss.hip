@@ -17,6 +17,7 @@
 
 #include "finenv.h"
 #include "finenv_dev.h"
+#include "finenv_host.h"
 
 namespace {
 
@@ -393,6 +394,7 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
 }  // namespace
 
 struct finenv_stoploss {
+    int device;           // HIP device that owns the bound state block (-1 before bind)
     finenv_stoploss_config cfg;
     finenv_stoploss_panel panel;
     finenv_stoploss_state st;
@@ -453,6 +455,7 @@ int finenv_stoploss_create(const finenv_stoploss_config *cfg, finenv_stoploss **
     finenv_stoploss *h = new (std::nothrow) finenv_stoploss;
     if (!h) return FINENV_ERR_NOMEM;
     memset(h, 0, sizeof(*h));
+    h->device = -1;
     h->cfg = *cfg;
     h->D = (int)D;
     h->magicN = N >= 2 ? (uint32_t)(((1ull << 32) + N - 1) / (unsigned long long)N) : 0u;
@@ -476,6 +479,7 @@ int finenv_stoploss_bind(finenv_stoploss *h, const finenv_stoploss_panel *panel,
         return sl_fail(h, FINENV_ERR_INVALID, "bind: null pointer");
     h->panel = *panel;
     h->st = *st;
+    h->device = finenv_host::pointer_device(st->f64);
     h->bound = 1;
     return FINENV_OK;
 }
@@ -484,6 +488,7 @@ int finenv_stoploss_reset(finenv_stoploss *h, const uint8_t *mask, float *obs_ou
 {
     if (!h) return FINENV_ERR_INVALID;
     if (!h->bound) return sl_fail(h, FINENV_ERR_UNBOUND, "reset: bind first");
+    const finenv_host::DeviceGuard guard(h->device);
     SlParams p = sl_params(h);
     p.mask = mask;
     p.obs = obs_out;
@@ -497,6 +502,7 @@ int finenv_stoploss_step(finenv_stoploss *h, const float *actions, float *obs, f
 {
     if (!h) return FINENV_ERR_INVALID;
     if (!h->bound) return sl_fail(h, FINENV_ERR_UNBOUND, "step: bind first");
+    const finenv_host::DeviceGuard guard(h->device);
     if (!actions || !obs || !reward || !done)
         return sl_fail(h, FINENV_ERR_INVALID, "step: null actions/obs/reward/done");
     SlParams p = sl_params(h);
