@@ -191,13 +191,13 @@ template <bool QUAD>
 int launch_rolling(const RiskParams &p, int n_blocks, hipStream_t stream)
 {
     const size_t lds = QUAD ? risk_lds_bytes(p.N) : sizeof(double) * (size_t)p.N;
-    static bool raised = false;
-    if (QUAD && lds > 64 * 1024 && !raised) {
+    // > 64 KiB of dynamic LDS needs an explicit opt-in (rare call: set it on every such launch,
+    // it is per device)
+    if (QUAD && lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&rolling_risk_kernel<QUAD>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)risk_lds_bytes(FINENV_RISKPRE_MAX_ASSETS)) != hipSuccess)
             return FINENV_ERR_HIP;
-        raised = true;
     }
     hipLaunchKernelGGL((rolling_risk_kernel<QUAD>), dim3((unsigned)n_blocks), dim3(kThreads), lds,
                        stream, p);

@@ -215,13 +215,16 @@ int launch_step(finenv_stock *h, const Params &p, hipStream_t stream)
         hipLaunchKernelGGL((np32::stock_step_kernel<TURB, STATS>), grid, block, lds, stream, p);
     } else {
         constexpr size_t lds = sizeof(float) * (np128::kR1 + np128::kR2 + np128::kR3);
-        static bool attr_set = false;      // > 64 KiB of dynamic LDS needs an explicit opt-in
-        if (!attr_set) {
+        // > 64 KiB of dynamic LDS needs an explicit opt-in, once per device (a process may
+        // hold handles on several GPUs)
+        static unsigned long long attr_set_mask = 0ull;
+        const int dev = h->device >= 0 && h->device < 64 ? h->device : 0;
+        if (!((attr_set_mask >> dev) & 1ull)) {
             if (hipFuncSetAttribute(
                     reinterpret_cast<const void *>(&np128::stock_step_kernel<TURB, STATS>),
                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return -1;
-            attr_set = true;
+            attr_set_mask |= 1ull << dev;
         }
         hipLaunchKernelGGL((np128::stock_step_kernel<TURB, STATS>), grid, block, lds, stream, p);
     }
