@@ -153,12 +153,14 @@ class VecStockTradingEnv:
                                                  self._stream()), self._h, "observe")
         return self.obs
 
-    def step(self, actions):
+    def step(self, actions, out=None):
         """One step() (:220-357) for every env, asynchronously on the current stream.
 
         actions: float32 [E, N] CUDA tensor.  Returns (obs, reward, done, info) where the
         first three are views of persistent device tensors, overwritten by the next call
         (clone them to keep).  No host synchronisation happens here.
+        out = (obs [E, D] f32, reward [E] f32, done [E] u8): write there instead (rollout
+        buffers: the kernel writes straight into slice t, no staging copy).
         """
         torch = _torch()
         if actions.dtype != torch.float32 or not actions.is_contiguous() or \
@@ -176,11 +178,16 @@ class VecStockTradingEnv:
                 C.c_void_p(self.term_obs.data_ptr()) if self.term_obs is not None else None,
                 C.c_void_p(self.realised.data_ptr()) if self.realised is not None else None))
         _, fn, outs = self._step_args
+        ret = (self.obs, self.reward, self.done)
+        if out is not None:
+            ret = out
+            outs = (C.c_void_p(out[0].data_ptr()), C.c_void_p(out[1].data_ptr()),
+                    C.c_void_p(out[2].data_ptr())) + outs[3:]
         rc = fn(self._h, C.c_void_p(actions.data_ptr()), *outs, int(self.auto_reset),
                 self._stream())
         if rc:
             nat.check(rc, self._h, "step")
-        return self.obs, self.reward, self.done, None
+        return ret[0], ret[1], ret[2], None
 
     # ------------------------------------------------------------------ introspection
     def episode_stats(self):

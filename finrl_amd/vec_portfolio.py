@@ -91,18 +91,19 @@ class VecStockPortfolioEnv:
                                                    self._stream()), self._h, "reset", "portfolio")
         return self.obs
 
-    def step(self, actions):
+    def step(self, actions, out=None):
         import torch
         if actions.dtype != torch.float32 or not actions.is_contiguous() or \
                 actions.device != self.obs.device:
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        obs, rew, done = out if out is not None else (self.obs, self.reward, self.done)
         nat.check(nat.lib().finenv_portfolio_step(
-            self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(self.obs.data_ptr()),
-            C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr()),
+            self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(obs.data_ptr()),
+            C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()),
             C.c_void_p(self.term_obs.data_ptr()) if self.term_obs is not None else None,
             C.c_void_p(self.weights.data_ptr()) if self.weights is not None else None,
             int(self.auto_reset), self._stream()), self._h, "step", "portfolio")
-        return self.obs, self.reward, self.done, None
+        return obs, rew, done, None
 
     def state_numpy(self):
         return {k: v.detach().cpu().numpy() for k, v in self.state.items()}

@@ -64,3 +64,36 @@ def test_graphed_segment_equals_eager_and_is_replayable():
     t_eager = (time.perf_counter() - t0) / 20
     print(f"segment of {n_steps} steps x {E} envs: eager {t_eager * 1e6:.0f} us, graph {t_graph * 1e6:.0f} us")
     assert t_graph < t_eager
+
+
+def test_stock_env_segment_in_graph_matches_eager():
+    """The headline env through the same capture path (its step() takes out= as well)."""
+    _need_gpu()
+    import bench
+    from finrl_amd import StockPanel
+    from finrl_amd.graph import GraphedSegment
+    from finrl_amd.rollout import RolloutBuffer
+    from finrl_amd.vec_env import VecStockTradingEnv
+    close, tech, risk = bench.synth_panel()
+    close, tech, risk = close[:40], tech[:40], risk[:40]        # episodes roll over inside a segment
+    E, N, n_steps = 2048, 30, 24
+    envs = [VecStockTradingEnv(StockPanel(close, tech, risk), E, **bench.ENV_KW) for _ in range(2)]
+    w = torch.randn(envs[0].obs.shape[1], N, device="cuda") * 1e-6
+
+    def policy(obs):
+        a = torch.tanh(obs @ w)
+        return a, a.sum(1), a.mean(1)
+
+    bufs = [RolloutBuffer(n_steps, E, envs[0].obs.shape[1], N) for _ in range(2)]
+    o0, o1 = envs[0].reset().clone(), envs[1].reset().clone()
+    seg = GraphedSegment(envs[1], policy, bufs[1])
+    for rep in range(2):
+        last0 = bufs[0].collect(envs[0], policy, o0).clone()
+        seg.replay(o1)
+        for name in ("obs", "actions", "rewards", "dones"):
+            assert torch.equal(getattr(bufs[0], name), getattr(bufs[1], name)), (rep, name)
+        for k in envs[0].state:
+            assert torch.equal(envs[0].state[k], envs[1].state[k]), (rep, k)
+        if rep == 1:
+            assert int(bufs[0].dones.sum()) > 0                  # an episode boundary was crossed
+        o0, o1 = last0, bufs[1].obs[n_steps].clone()
