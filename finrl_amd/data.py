@@ -5,6 +5,9 @@ Vectorised restatements -- same results as the reference helpers, no network, no
   data_split   <- finrl/meta/preprocessor/preprocessors.py:24-33
   df_to_array  <- finrl/meta/data_processors/processor_yahoofinance.py:293-318 plus the
                   NaN / inf -> 0 clean-up of finrl/meta/data_processor.py:74-84
+  clean_data   <- finrl/meta/preprocessor/preprocessors.py:107-131 (FeatureEngineer.clean_data:
+                  keep only tickers with a close on every date -- what makes the panel complete
+                  before add_turbulence / the envs see it)
 """
 from __future__ import annotations
 
@@ -17,6 +20,17 @@ def data_split(df, start, end, target_date_col="date"):
     data = data.sort_values([target_date_col, "tic"], ignore_index=True)
     data.index = data[target_date_col].factorize()[0]
     return data
+
+
+def clean_data(data):
+    """Rows sorted by (date, tic), index = day ordinal, tickers with a missing close on any
+    date dropped (delisted / not yet listed)."""
+    df = data.copy()
+    df = df.sort_values(["date", "tic"], ignore_index=True)
+    df.index = df.date.factorize()[0]
+    closes = df.pivot_table(index="date", columns="tic", values="close")
+    keep = closes.columns[closes.notna().all(axis=0)]
+    return df[df.tic.isin(keep)]
 
 
 def df_to_array(df, tech_indicator_list, if_vix, price_col="adjcp"):

@@ -76,3 +76,11 @@ def test_matches_reference_functions():
     a = pre.data_split(df, "2020-01-02", "2020-01-08")
     b = data_split(df, "2020-01-02", "2020-01-08")
     pd.testing.assert_frame_equal(a, b)
+    # FeatureEngineer.clean_data (:107-131) on a ragged frame: one ticker misses a date, one a close
+    from finrl_amd.data import clean_data
+    t_a, t_b = sorted(df.tic.unique())[:2]
+    ragged = df.drop(df.index[(df.tic == t_a) & (df.date == df.date.max())]).copy()
+    ragged.loc[(ragged.tic == t_b) & (ragged.date == ragged.date.min()), "close"] = np.nan
+    fe = pre.FeatureEngineer(use_technical_indicator=False)
+    pd.testing.assert_frame_equal(fe.clean_data(ragged), clean_data(ragged))
+    assert clean_data(ragged).tic.nunique() == df.tic.nunique() - 2
