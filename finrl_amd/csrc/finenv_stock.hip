@@ -102,6 +102,16 @@ namespace np32 {
 #undef FINENV_SORTNET
 }  // namespace np32
 
+namespace np64 {
+#define FINENV_NP 64
+#define FINENV_LOG2NP 6
+#define FINENV_SORTNET "sortnet64.inc"
+#include "finenv_stock_kernels.inc"
+#undef FINENV_NP
+#undef FINENV_LOG2NP
+#undef FINENV_SORTNET
+}  // namespace np64
+
 namespace np128 {
 #define FINENV_NP 128
 #define FINENV_LOG2NP 7
@@ -199,6 +209,9 @@ int launch_aux(finenv_stock *h, const Params &p, int mode, hipStream_t stream)
     if (h->cfg.n_tickers <= 32)
         hipLaunchKernelGGL(np32::stock_aux_kernel, aux_grid<np32::kAuxWaves>(h->cfg.n_envs),
                            dim3(kWave * np32::kAuxWaves), 0, stream, p, mode);
+    else if (h->cfg.n_tickers <= 64)
+        hipLaunchKernelGGL(np64::stock_aux_kernel, aux_grid<np64::kAuxWaves>(h->cfg.n_envs),
+                           dim3(kWave * np64::kAuxWaves), 0, stream, p, mode);
     else
         hipLaunchKernelGGL(np128::stock_aux_kernel, aux_grid<np128::kAuxWaves>(h->cfg.n_envs),
                            dim3(kWave * np128::kAuxWaves), 0, stream, p, mode);
@@ -213,6 +226,11 @@ int launch_step(finenv_stock *h, const Params &p, hipStream_t stream)
     if (h->cfg.n_tickers <= 32) {
         constexpr size_t lds = sizeof(float) * (np32::kR1 + np32::kR2 + np32::kR3);
         hipLaunchKernelGGL((np32::stock_step_kernel<TURB, STATS>), grid, block, lds, stream, p);
+    } else if (h->cfg.n_tickers <= 64) {
+        // 33..64 tickers: the 128-wide code paths at half the padding -- 34 KB of LDS, four
+        // blocks per CU (all 1024 resident at 65,536 envs) instead of two
+        constexpr size_t lds = sizeof(float) * (np64::kR1 + np64::kR2 + np64::kR3);
+        hipLaunchKernelGGL((np64::stock_step_kernel<TURB, STATS>), grid, block, lds, stream, p);
     } else {
         constexpr size_t lds = sizeof(float) * (np128::kR1 + np128::kR2 + np128::kR3);
         // > 64 KiB of dynamic LDS needs an explicit opt-in, once per device (a process may

@@ -81,7 +81,7 @@ typedef struct finenv_stock_panel {
     const float    *obs_tmpl;     /* [T][D]  f32 observation rows with the cash and
                                      holdings slots zero: f32(close) and f32(tech) in obs
                                      order (what DummyVecEnv's float32 buffer would hold) */
-    const uint32_t *untradable;   /* [T][W]  W = 1 (N <= 32) or 4 (N <= 128) words per day;
+    const uint32_t *untradable;   /* [T][W]  W = 1 (N <= 32) or 4 (33 <= N <= 128) words per day;
                                      bit i set <=> first indicator of ticker i
                                      == 1.0 on that day (the fork's `!= True` test,
                                      :105, :174), evaluated on the fp64 values           */

@@ -113,6 +113,10 @@ def _random_panel(seed, T, N, K, flag_frac=0.03):
     dict(E=200, T=14, N=100, K=8, steps=32, thr=40.0, cash=400_000, hmax=100),
     dict(E=70, T=10, N=33, K=1, steps=24, thr=None, cash=50_000, hmax=50),
     dict(E=64, T=9, N=128, K=1, steps=20, thr=None, cash=900_000, hmax=200),
+    # 64-wide variant (33..64 tickers)
+    dict(E=300, T=16, N=50, K=4, steps=36, thr=35.0, cash=200_000, hmax=100),
+    dict(E=129, T=11, N=64, K=2, steps=26, thr=None, cash=80_000, hmax=300),
+    dict(E=70, T=10, N=65, K=1, steps=24, thr=None, cash=50_000, hmax=50),
 ])
 def test_hip_matches_oracle_random_batch(cfg):
     """Distinct action streams per env, DummyVecEnv auto-reset semantics, per-env initial
