@@ -167,6 +167,11 @@ class VecCashPenaltyEnv:
             int(self.auto_reset), self._stream()), self._h, "step", self._kind)
         return obs, rew, done, None
 
+    def as_sb3_vec_env(self):
+        """stable-baselines3 VecEnv-shaped view (numpy in / out, auto-reset, terminal_observation)."""
+        from .vec_env import SB3VecEnvAdapter
+        return SB3VecEnvAdapter(self)
+
     def state_numpy(self):
         out = {k: v.detach().cpu().numpy() for k, v in self.state.items()}
         for k in self._books:

@@ -228,7 +228,9 @@ class SB3VecEnvAdapter:
     with auto-reset and ``infos[i]["terminal_observation"]``.
     """
 
-    def __init__(self, env: VecStockTradingEnv):
+    def __init__(self, env):
+        """env: any of the batched envs of this package (they share the tensor protocol:
+        ``reset()``, ``step(a) -> (obs, reward, done, _)``, ``enable_terminal_obs()``)."""
         self.env = env
         env.auto_reset = True
         env.enable_terminal_obs()
@@ -273,7 +275,8 @@ class SB3VecEnvAdapter:
         return [seed] * self.num_envs
 
     def render(self, mode="human"):
-        return self.env.observe().cpu().numpy()
+        obs = self.env.observe() if hasattr(self.env, "observe") else self.env.obs
+        return obs.cpu().numpy()
 
     def env_is_wrapped(self, wrapper_class, indices=None):
         return [False] * self.num_envs

@@ -105,5 +105,10 @@ class VecStockPortfolioEnv:
             int(self.auto_reset), self._stream()), self._h, "step", "portfolio")
         return obs, rew, done, None
 
+    def as_sb3_vec_env(self):
+        """stable-baselines3 VecEnv-shaped view (numpy in / out, auto-reset, terminal_observation)."""
+        from .vec_env import SB3VecEnvAdapter
+        return SB3VecEnvAdapter(self)
+
     def state_numpy(self):
         return {k: v.detach().cpu().numpy() for k, v in self.state.items()}

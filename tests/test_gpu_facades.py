@@ -137,3 +137,31 @@ def test_dollar_env_facades_replay_reference_episode(kind):
     assert obs0.shape == (1, env.state_space)
     o, r, d, infos = vec.step(np.zeros((1, N), np.float32))
     assert o.shape == (1, env.state_space) and r.shape == (1,) and isinstance(infos[0], dict)
+
+
+def test_sb3_adapter_over_sibling_vec_envs():
+    """The VecEnv-shaped adapter (numpy in / out, auto-reset, terminal_observation) over the crypto
+    and cash-penalty batches: protocol shapes, and terminal observations at episode ends."""
+    _need_gpu()
+    from finrl_amd.vec_cashpenalty import CashPenaltyPanel, VecCashPenaltyEnv
+    from finrl_amd.vec_crypto import VecCryptoEnv
+    rng = np.random.default_rng(0)
+    T, N, W, E = 12, 4, 6, 70
+    price = 100 * np.exp(np.cumsum(rng.normal(0, 0.01, (T, N)), axis=0))
+    crypto = VecCryptoEnv({"price_array": price, "tech_array": rng.normal(0, 100, (T, W))}, E)
+    info = rng.normal(0, 1, (T, N, 2))
+    cash = VecCashPenaltyEnv(CashPenaltyPanel(price, info), E, hmax=5_000, random_start=False)
+    for env in (crypto, cash):
+        venv = env.as_sb3_vec_env()
+        obs = venv.reset()
+        D = obs.shape[1]
+        assert obs.shape == (E, D) and obs.dtype == np.float32 and venv.num_envs == E
+        seen_done = 0
+        for s in range(2 * T):
+            obs, rew, done, infos = venv.step(rng.uniform(-1, 1, (E, N)).astype(np.float32))
+            assert obs.shape == (E, D) and rew.shape == (E,) and done.dtype == bool
+            assert len(infos) == E
+            for i in np.nonzero(done)[0]:
+                assert infos[i]["terminal_observation"].shape == (D,)
+            seen_done += int(done.sum())
+        assert seen_done >= E
