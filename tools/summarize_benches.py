@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/SUMMARY.md: one table over the latest bench lines and rocprofv3 kernel averages kept
-under profiles/ (usage: python tools/summarize_benches.py r01_h)."""
+under profiles/ (usage: python tools/summarize_benches.py r01_i)."""
 import csv
 import glob
 import json
@@ -21,7 +21,7 @@ def kernel_avg(path, needle):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01_h"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01_i"
     rows = []
     b = json.load(open(os.path.join(P, f"{tag}_bench.json")))
     rows.append(("StockTradingEnv (headline, DOW30 x 8)", b, kernel_avg(
