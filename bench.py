@@ -78,6 +78,40 @@ def cpu_baseline(close, tech, risk, budget_s=12.0):
                        f"(host has {os.cpu_count()} cores)")
 
 
+def parity_sample(close, tech, risk, dev, n_envs=256, n_steps=300):
+    """Second half of BASELINE.json's metric ("reward max|delta| vs ref"), measured live inside
+    the cpu_baseline leg: the oracle (pinned bit-exact to the reference) and the HIP env replay the
+    same random action streams; reports the worst differences over all envs and steps."""
+    import torch
+    from finrl_amd import StockPanel
+    from finrl_amd.vec_env import VecStockTradingEnv
+    from oracle.stock import StockOracle
+    Ts = min(close.shape[0], 120)              # two episode ends inside n_steps
+    c, t, r = close[:Ts], tech[:Ts], risk[:Ts]
+    orc = StockOracle(c, t, r, n_envs=n_envs, **ENV_KW)
+    env = VecStockTradingEnv(StockPanel(c, t, r), n_envs, device=dev, **ENV_KW)
+    ok_obs = bool(np.array_equal(env.reset().cpu().numpy(), orc.reset().astype(np.float32)))
+    rng = np.random.default_rng(99)
+    d_rew = d_asset = 0.0
+    n_hold = n_done = n_tot = 0
+    for s in range(n_steps):
+        a = rng.uniform(-1, 1, (n_envs, close.shape[1])).astype(np.float32)
+        g_obs, g_rew, g_done, _ = env.step(torch.from_numpy(a).to(dev))
+        o_obs, o_rew, o_done, _ = orc.vec_step(a)
+        d_rew = max(d_rew, float(np.max(np.abs(g_rew.cpu().numpy().astype(np.float64) - o_rew.astype(np.float32)))))
+        st, os_ = env.state_numpy(), orc.state()
+        ga = st["cash"] + (st["shares"] * c[st["day"]]).sum(1)
+        oa = os_["cash"] + (os_["shares"] * c[os_["day"]]).sum(1)
+        d_asset = max(d_asset, float(np.max(np.abs(ga - oa) / np.abs(oa))))
+        n_hold += int((st["shares"] == os_["shares"]).all(1).sum())
+        n_done += int((g_done.cpu().numpy().astype(bool) == o_done).sum())
+        n_tot += n_envs
+        ok_obs = ok_obs and bool(np.array_equal(g_obs.cpu().numpy(), o_obs.astype(np.float32)))
+    return dict(envs=n_envs, steps=n_steps, reward_max_abs_delta=d_rew,
+                total_asset_max_rel_delta=d_asset, holdings_match_rate=n_hold / n_tot,
+                done_match_rate=n_done / n_tot, observations_identical=ok_obs)
+
+
 def cpu_baseline_threads(close, tech, risk, n_threads, budget_s=6.0):
     """Same oracle, one independent env shard per thread (ctypes releases the GIL inside the C
     call): what the host cores this process may use deliver together.  Reported beside
@@ -341,6 +375,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(close, tech, risk)
+            out["cpu_baseline"]["parity_sample"] = parity_sample(close, tech, risk, dev)
             nthr = max(1, min(16, len(os.sched_getaffinity(0))))    # the box's CPU share for one GPU
             if nthr > 1:
                 out["cpu_baseline_all_cores"] = cpu_baseline_threads(close, tech, risk, nthr)
