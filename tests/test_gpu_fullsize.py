@@ -135,3 +135,43 @@ def test_fullsize_episode_rollover_checksum():
             assert bool((env.state["day"] == 0).all()) and bool((env.state["trades"] == 0).all())
     assert n_done == 2
     assert bool((env.state["episode"] == 3).all())           # initial reset + 2 auto-resets
+
+
+def test_fullsize_two_full_episodes_sampled_oracle():
+    """The bench workload end to end: 65,536 envs, the full T=2893 panel, two whole episodes
+    (5,786 steps, two in-launch auto-resets, the cash-bound late-episode regime included); 192
+    sampled envs are compared with the oracle at every step (observations, rewards, dones) and
+    in their final state and Sharpe sums."""
+    _need_gpu()
+    import bench
+    from finrl_amd import StockPanel
+    from finrl_amd.vec_env import VecStockTradingEnv
+    from oracle.stock import StockOracle
+    close, tech, risk = _panel()
+    T, N = close.shape
+    env = VecStockTradingEnv(StockPanel(close, tech, risk), E, **bench.ENV_KW)
+    sample = np.sort(np.random.default_rng(5).choice(E, 192, replace=False))
+    sample[:4] = [0, 63, 64, E - 1]
+    sample = np.unique(sample)
+    idx = torch.from_numpy(sample).cuda()
+    orc = StockOracle(close, tech, risk, n_envs=len(sample), **bench.ENV_KW)
+    env.reset(); orc.reset()
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(2893)
+    n_done = 0
+    for s in range(2 * T):
+        a = torch.rand(E, N, generator=gen, device="cuda") * 2 - 1
+        obs, rew, done, _ = env.step(a)
+        o_obs, o_rew, o_done, _ = orc.vec_step(a[idx].cpu().numpy())
+        if not (np.array_equal(obs[idx].cpu().numpy(), o_obs.astype(np.float32)) and
+                np.array_equal(rew[idx].cpu().numpy(), o_rew.astype(np.float32)) and
+                np.array_equal(done[idx].cpu().numpy().astype(bool), o_done)):
+            pytest.fail(f"mismatch at step {s}")
+        n_done += int(o_done.all())
+    assert n_done == 2
+    st, os_ = env.state, orc.state()
+    np.testing.assert_array_equal(st["cash"][idx].cpu().numpy(), os_["cash"])
+    np.testing.assert_array_equal(st["cost"][idx].cpu().numpy(), os_["cost"])
+    np.testing.assert_array_equal(st["holdings"].T[idx].cpu().numpy(), os_["shares"])
+    np.testing.assert_array_equal(st["trades"][idx].cpu().numpy(), os_["trades"])
+    assert bool((st["episode"] == 3).all())
