@@ -260,55 +260,113 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
 
     // sells then buys, ticker index order (:112-129); liquidation when turbulent (:131-134)
     constexpr int kPB = 8;                    // price loads per batch
-    for (int i0 = 0; i0 < N; i0 += kPB) {
-        float prb[kPB];
+    // Steady state: once an env has traded an integer share count its cash is a np.float64 and
+    // stays one (float64 dominates every later promotion).  When that holds for the whole wave the
+    // trade loops run on plain doubles -- the per-operation dtype dispatch of Num (both roundings
+    // computed, tag-selected) is most of this kernel's arithmetic; any other tag mix takes the
+    // generic loops below.  Same operations, same order, same roundings in both.
+    if (__all(amount.tag == FINENV_NT_F64)) {
+        double amt = amount.v;
+        for (int i0 = 0; i0 < N; i0 += kPB) {
+            float prb[kPB];
 #pragma unroll
-        for (int j = 0; j < kPB; ++j) prb[j] = *at(p.panel.price, pb + (unsigned)min(i0 + j, N - 1));
+            for (int j = 0; j < kPB; ++j) prb[j] = *at(p.panel.price, pb + (unsigned)min(i0 + j, N - 1));
 #pragma unroll
-        for (int j = 0; j < kPB; ++j) pin(prb[j]);
+            for (int j = 0; j < kPB; ++j) pin(prb[j]);
 #pragma unroll
-        for (int j = 0; j < kPB; ++j) {
-        const int i = i0 + j;
-        if (i >= N) break;
-        const int a = (int)(arow[i] * ms);                                        // :104
-        const float pr = prb[j];
-        if (calm && a < -min_action && pr > 0.0f) {
-            const float s = scol[i * kWave];
-            const double want = (double)(-a);
-            const bool is_int = want < (double)s;            // min(stocks, -a) -> -a (np.int64)
-            const double sell = is_int ? want : (double)s;
-            scol[i * kWave] = (float)((double)s - sell);
-            // price(f32) * sell: int64 operand -> float64; float32 operand -> float32
-            const Num t0 = is_int ? mk((double)pr * sell, FINENV_NT_F64)
-                                  : mk((double)(pr * (float)sell), FINENV_NT_F32);
-            amount = n_add(amount, n_mul(t0, one_m));
-            ccol[i * kWave] = 0.0f;
+            for (int j = 0; j < kPB; ++j) {
+                const int i = i0 + j;
+                if (i >= N) break;
+                const int a = (int)(arow[i] * ms);                                // :104
+                const float pr = prb[j];
+                if (calm && a < -min_action && pr > 0.0f) {
+                    const float s = scol[i * kWave];
+                    const double want = (double)(-a);
+                    const bool is_int = want < (double)s;        // min(stocks, -a) -> -a (np.int64)
+                    const double sell = is_int ? want : (double)s;
+                    scol[i * kWave] = (float)((double)s - sell);
+                    // int64 share count: float64 product chain; float32 count: float32 chain
+                    const double term = is_int ? ((double)pr * sell) * one_m.v
+                                               : (double)((pr * (float)sell) * (float)one_m.v);
+                    amt = amt + term;
+                    ccol[i * kWave] = 0.0f;
+                }
+            }
         }
+        for (int i0 = 0; i0 < N; i0 += kPB) {
+            float prb[kPB];
+#pragma unroll
+            for (int j = 0; j < kPB; ++j) prb[j] = *at(p.panel.price, pb + (unsigned)min(i0 + j, N - 1));
+#pragma unroll
+            for (int j = 0; j < kPB; ++j) pin(prb[j]);
+#pragma unroll
+            for (int j = 0; j < kPB; ++j) {
+                const int i = i0 + j;
+                if (i >= N) break;
+                const int a = (int)(arow[i] * ms);
+                const float pr = prb[j];
+                if (calm && a > min_action && pr > 0.0f) {
+                    const double q = floordiv_true(amt, (double)pr);              // amount // price
+                    const double buy = ((double)a < q) ? (double)a : q;           // min(q, a)
+                    const float s = scol[i * kWave];
+                    scol[i * kWave] = (float)((double)s + buy);
+                    amt = amt - (((double)pr * buy) * one_p.v);
+                    ccol[i * kWave] = 0.0f;
+                }
+            }
         }
-    }
-    for (int i0 = 0; i0 < N; i0 += kPB) {
-        float prb[kPB];
-#pragma unroll
-        for (int j = 0; j < kPB; ++j) prb[j] = *at(p.panel.price, pb + (unsigned)min(i0 + j, N - 1));
-#pragma unroll
-        for (int j = 0; j < kPB; ++j) pin(prb[j]);
-#pragma unroll
-        for (int j = 0; j < kPB; ++j) {
-        const int i = i0 + j;
-        if (i >= N) break;
-        const int a = (int)(arow[i] * ms);
-        const float pr = prb[j];
-        if (calm && a > min_action && pr > 0.0f) {
-            const Num q = n_floordiv(amount, mk((double)pr, FINENV_NT_F32));      // amount // price
-            const bool is_int = (double)a < q.v;             // min(q, a) -> a (np.int64)
-            const double buy = is_int ? (double)a : q.v;
-            const Num t0 = is_int ? mk((double)pr * buy, FINENV_NT_F64)
-                                  : n_mul(mk((double)pr, FINENV_NT_F32), q);
-            const float s = scol[i * kWave];
-            scol[i * kWave] = (float)((double)s + buy);
-            amount = n_sub(amount, n_mul(t0, one_p));
-            ccol[i * kWave] = 0.0f;
+        amount = mk(amt, FINENV_NT_F64);
+    } else {
+        for (int i0 = 0; i0 < N; i0 += kPB) {
+            float prb[kPB];
+    #pragma unroll
+            for (int j = 0; j < kPB; ++j) prb[j] = *at(p.panel.price, pb + (unsigned)min(i0 + j, N - 1));
+    #pragma unroll
+            for (int j = 0; j < kPB; ++j) pin(prb[j]);
+    #pragma unroll
+            for (int j = 0; j < kPB; ++j) {
+            const int i = i0 + j;
+            if (i >= N) break;
+            const int a = (int)(arow[i] * ms);                                        // :104
+            const float pr = prb[j];
+            if (calm && a < -min_action && pr > 0.0f) {
+                const float s = scol[i * kWave];
+                const double want = (double)(-a);
+                const bool is_int = want < (double)s;            // min(stocks, -a) -> -a (np.int64)
+                const double sell = is_int ? want : (double)s;
+                scol[i * kWave] = (float)((double)s - sell);
+                // price(f32) * sell: int64 operand -> float64; float32 operand -> float32
+                const Num t0 = is_int ? mk((double)pr * sell, FINENV_NT_F64)
+                                      : mk((double)(pr * (float)sell), FINENV_NT_F32);
+                amount = n_add(amount, n_mul(t0, one_m));
+                ccol[i * kWave] = 0.0f;
+            }
+            }
         }
+        for (int i0 = 0; i0 < N; i0 += kPB) {
+            float prb[kPB];
+    #pragma unroll
+            for (int j = 0; j < kPB; ++j) prb[j] = *at(p.panel.price, pb + (unsigned)min(i0 + j, N - 1));
+    #pragma unroll
+            for (int j = 0; j < kPB; ++j) pin(prb[j]);
+    #pragma unroll
+            for (int j = 0; j < kPB; ++j) {
+            const int i = i0 + j;
+            if (i >= N) break;
+            const int a = (int)(arow[i] * ms);
+            const float pr = prb[j];
+            if (calm && a > min_action && pr > 0.0f) {
+                const Num q = n_floordiv(amount, mk((double)pr, FINENV_NT_F32));      // amount // price
+                const bool is_int = (double)a < q.v;             // min(q, a) -> a (np.int64)
+                const double buy = is_int ? (double)a : q.v;
+                const Num t0 = is_int ? mk((double)pr * buy, FINENV_NT_F64)
+                                      : n_mul(mk((double)pr, FINENV_NT_F32), q);
+                const float s = scol[i * kWave];
+                scol[i * kWave] = (float)((double)s + buy);
+                amount = n_sub(amount, n_mul(t0, one_p));
+                ccol[i * kWave] = 0.0f;
+            }
+            }
         }
     }
     if (!calm) {
