@@ -26,7 +26,7 @@ constexpr int kMaxN = FINENV_STOCKNP_MAX_TICKERS;
 constexpr int kRowA = kMaxN + 1;                       // action rows, stride 33
 constexpr int kRowH = 2 * kMaxN + 1;                   // obs heads [amount|stocks|cool], stride 65
 constexpr int kWaves = 4;
-constexpr int kLdsPerWave = kWave * kRowH + 2 * kMaxN * kWave;   // heads/actions + stocks + cool
+constexpr int kLdsPerWave = kWave * kRowH + 2 * kMaxN * kWave + kMaxN;   // heads/actions + stocks + cool + price row
 
 struct NpParams {
     finenv_stocknp_config cfg;
@@ -118,9 +118,31 @@ __device__ __forceinline__ void np_write_rows(float *__restrict__ dst, const NpP
 }
 
 // (stocks * price).sum() in float32, NumPy pairwise order (8 accumulators, n < 128)
+// prow != nullptr: the wave's envs share the day and its price row sits in LDS (one coalesced
+// load for the whole step instead of a global round trip per batch of 8 tickers)
 __device__ __forceinline__ float holdings_value(const float *scol, const float *__restrict__ price,
-                                                unsigned pb, int N)
+                                                unsigned pb, int N, const float *prow = nullptr)
 {
+    if (prow != nullptr) {                   // LDS row: same sums, no global load
+        auto prodl = [&](int i) { return scol[i * kWave] * prow[i]; };
+        float suml;
+        if (N < 8) {
+            suml = 0.0f;
+            for (int i = 0; i < N; ++i) suml += prodl(i);
+        } else {
+            float r8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r8[j] = prodl(j);
+            const int full = N - (N & 7);
+            for (int i = 8; i < full; i += 8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r8[j] += prodl(i + j);
+            }
+            suml = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+            for (int i = full; i < N; ++i) suml += prodl(i);
+        }
+        return suml;
+    }
     auto prod = [&](int i) { return scol[i * kWave] * *at(price, pb + (unsigned)i); };
     float sum;
     if (N < 8) {
@@ -163,6 +185,7 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
     const int e = valid ? e0 + lane : e0;
     float *scol = stk + lane, *ccol = cdl + lane;
     float *head = heads + lane * kRowH;
+    float *prow_lds = cdl + kMaxN * kWave;                 // [ticker] shared price row (lock-step days)
 
     // reset(): day 0, start state, total_asset = amount + (stocks*price[0]).sum()  (:80-101)
     auto do_reset = [&](Num &amount, Num &ta, Num &gr, Num &ita) {
@@ -232,6 +255,11 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
     Num ita = mk(NF(FINENV_NF_INITIAL_TOTAL_ASSET), (tags >> 6) & 3);
     const int day = NI(FINENV_NI_DAY) + 1;                                        // :106
     const unsigned pb = (unsigned)(day * N);
+    const int day0 = __builtin_amdgcn_readfirstlane(day);
+    const bool uni = __all(day == day0);                   // lock-step batch: one price row per wave
+    if (uni && lane < kMaxN)
+        prow_lds[lane] = *at(p.panel.price, (unsigned)(day0 * N + min(lane, N - 1)));
+    const float *prow = uni ? prow_lds : nullptr;
     // (global loads in batches, issued before their first use: a rolled loop exposes one HBM round
     //  trip per ticker at one wave per SIMD)
     for (int i0 = 0; i0 < N; i0 += 16) {
@@ -270,7 +298,15 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
         for (int i0 = 0; i0 < N; i0 += kPB) {
             float prb[kPB];
 #pragma unroll
-            for (int j = 0; j < kPB; ++j) prb[j] = *at(p.panel.price, pb + (unsigned)min(i0 + j, N - 1));
+            for (int j = 0; j < kPB; ++j) prb[j] = 0.0f;
+            if (uni) {                       // (a branch, not a select: no global load at all)
+#pragma unroll
+                for (int j = 0; j < kPB; ++j) prb[j] = prow_lds[min(i0 + j, N - 1)];
+            } else {
+#pragma unroll
+                for (int j = 0; j < kPB; ++j)
+                    prb[j] = *at(p.panel.price, pb + (unsigned)min(i0 + j, N - 1));
+            }
 #pragma unroll
             for (int j = 0; j < kPB; ++j) pin(prb[j]);
 #pragma unroll
@@ -296,7 +332,15 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
         for (int i0 = 0; i0 < N; i0 += kPB) {
             float prb[kPB];
 #pragma unroll
-            for (int j = 0; j < kPB; ++j) prb[j] = *at(p.panel.price, pb + (unsigned)min(i0 + j, N - 1));
+            for (int j = 0; j < kPB; ++j) prb[j] = 0.0f;
+            if (uni) {                       // (a branch, not a select: no global load at all)
+#pragma unroll
+                for (int j = 0; j < kPB; ++j) prb[j] = prow_lds[min(i0 + j, N - 1)];
+            } else {
+#pragma unroll
+                for (int j = 0; j < kPB; ++j)
+                    prb[j] = *at(p.panel.price, pb + (unsigned)min(i0 + j, N - 1));
+            }
 #pragma unroll
             for (int j = 0; j < kPB; ++j) pin(prb[j]);
 #pragma unroll
@@ -320,7 +364,15 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
         for (int i0 = 0; i0 < N; i0 += kPB) {
             float prb[kPB];
     #pragma unroll
-            for (int j = 0; j < kPB; ++j) prb[j] = *at(p.panel.price, pb + (unsigned)min(i0 + j, N - 1));
+            for (int j = 0; j < kPB; ++j) prb[j] = 0.0f;
+            if (uni) {                       // (a branch, not a select: no global load at all)
+#pragma unroll
+                for (int j = 0; j < kPB; ++j) prb[j] = prow_lds[min(i0 + j, N - 1)];
+            } else {
+#pragma unroll
+                for (int j = 0; j < kPB; ++j)
+                    prb[j] = *at(p.panel.price, pb + (unsigned)min(i0 + j, N - 1));
+            }
     #pragma unroll
             for (int j = 0; j < kPB; ++j) pin(prb[j]);
     #pragma unroll
@@ -346,7 +398,15 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
         for (int i0 = 0; i0 < N; i0 += kPB) {
             float prb[kPB];
     #pragma unroll
-            for (int j = 0; j < kPB; ++j) prb[j] = *at(p.panel.price, pb + (unsigned)min(i0 + j, N - 1));
+            for (int j = 0; j < kPB; ++j) prb[j] = 0.0f;
+            if (uni) {                       // (a branch, not a select: no global load at all)
+#pragma unroll
+                for (int j = 0; j < kPB; ++j) prb[j] = prow_lds[min(i0 + j, N - 1)];
+            } else {
+#pragma unroll
+                for (int j = 0; j < kPB; ++j)
+                    prb[j] = *at(p.panel.price, pb + (unsigned)min(i0 + j, N - 1));
+            }
     #pragma unroll
             for (int j = 0; j < kPB; ++j) pin(prb[j]);
     #pragma unroll
@@ -370,7 +430,7 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
         }
     }
     if (!calm) {
-        const Num t0 = mk((double)holdings_value(scol, p.panel.price, pb, N), FINENV_NT_F32);
+        const Num t0 = mk((double)holdings_value(scol, p.panel.price, pb, N, prow), FINENV_NT_F32);
         amount = n_add(amount, n_mul(t0, one_m));
         for (int i = 0; i < N; ++i) {
             scol[i * kWave] = 0.0f;
@@ -378,7 +438,7 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
         }
     }
     // total asset, reward, discounted return (:137-145)
-    Num ta = n_add(amount, mk((double)holdings_value(scol, p.panel.price, pb, N), FINENV_NT_F32));
+    Num ta = n_add(amount, mk((double)holdings_value(scol, p.panel.price, pb, N, prow), FINENV_NT_F32));
     Num r = n_mul(n_sub(ta, ta_old), mk(p.cfg.reward_scaling, FINENV_NT_PY));
     gr = n_add(n_mul(gr, mk(p.cfg.gamma, FINENV_NT_PY)), r);
     const bool done = day == p.cfg.n_days - 1;
