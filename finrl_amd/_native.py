@@ -244,6 +244,8 @@ def lib():
                                             C.c_int32, C.c_int32, C.c_void_p]
     L.finenv_riskpre_rolling_cov.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                              C.c_int32, C.c_void_p]
+    L.finenv_cashpenalty_set_random_start.argtypes = [C.c_void_p, C.c_int32, C.c_uint64]
+    L.finenv_stoploss_set_random_start.argtypes = [C.c_void_p, C.c_int32, C.c_uint64]
     if L.finenv_abi_version() != 2:
         raise NativeLibraryError("libfinenv.so ABI version mismatch; rebuild (make -C finrl_amd/csrc)")
     L.finenv_struct_size.argtypes = [C.c_int]

@@ -39,6 +39,8 @@ struct CpParams {
     int32_t auto_reset;
     int32_t D;
     uint32_t magicN;
+    int32_t rs_hi;                  // random_start: draw in [0, rs_hi) on the device (0 = off)
+    unsigned long long rs_seed;
 };
 
 #define KF(fld) (*at(p.st.f64, (unsigned)(fld) * (unsigned)E + (unsigned)e))
@@ -148,7 +150,8 @@ __global__ void __launch_bounds__(kWave *kWaves) cashpenalty_kernel(const CpPara
 
     if (RESET_ONLY) {                                                          // :131-157
         const bool sel = valid && (p.mask == nullptr || p.mask[e] != 0);
-        const int start = KI(FINENV_KI_NEXT_START);
+        const int start = p.rs_hi > 0 ? draw_start(p.rs_seed, e, KI(FINENV_KI_EPISODE) + 1, p.rs_hi)
+                                      : KI(FINENV_KI_NEXT_START);
         if (sel) {
             KI(FINENV_KI_START) = start;
             KI(FINENV_KI_DATE_INDEX) = start;
@@ -287,7 +290,8 @@ __global__ void __launch_bounds__(kWave *kWaves) cashpenalty_kernel(const CpPara
         if (p.auto_reset) {                                                      // reset()
             wave_sync();
             if (done) {
-                const int ns = KI(FINENV_KI_NEXT_START);
+                const int ns = p.rs_hi > 0 ? draw_start(p.rs_seed, e, KI(FINENV_KI_EPISODE) + 1, p.rs_hi)
+                                           : KI(FINENV_KI_NEXT_START);
                 di = ns;
                 row_day = ns;
                 coh = c.initial_amount;
@@ -325,6 +329,8 @@ __global__ void __launch_bounds__(kWave *kWaves) cashpenalty_kernel(const CpPara
 }  // namespace
 
 struct finenv_cashpenalty {
+    int32_t rs_hi;
+    unsigned long long rs_seed;
     int device;           // HIP device that owns the bound state block (-1 before bind)
     finenv_cashpenalty_config cfg;
     finenv_cashpenalty_panel panel;
@@ -359,6 +365,8 @@ CpParams kp_params(const finenv_cashpenalty *h)
     p.st = h->st;
     p.D = h->D;
     p.magicN = h->magicN;
+    p.rs_hi = h->rs_hi;
+    p.rs_seed = h->rs_seed;
     return p;
 }
 dim3 kp_grid(int E)
@@ -412,6 +420,14 @@ int finenv_cashpenalty_bind(finenv_cashpenalty *h, const finenv_cashpenalty_pane
     h->st = *st;
     h->device = finenv_host::pointer_device(st->f64);
     h->bound = 1;
+    return FINENV_OK;
+}
+
+int finenv_cashpenalty_set_random_start(finenv_cashpenalty *h, int32_t hi, uint64_t seed)
+{
+    if (!h || hi < 0 || hi > h->cfg.n_days) return FINENV_ERR_INVALID;
+    h->rs_hi = hi;
+    h->rs_seed = seed;
     return FINENV_OK;
 }
 

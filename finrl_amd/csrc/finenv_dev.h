@@ -35,6 +35,17 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Counter-based uniform draw in [0, hi): splitmix64 of (seed, env, episode), multiply-shift.
+__device__ __forceinline__ int draw_start(unsigned long long seed, int env, int episode, int hi)
+{
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(unsigned)env +
+                           0xD1B54A32D192ED03ull * (unsigned long long)(unsigned)episode;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (int)(((z >> 32) * (unsigned long long)(unsigned)hi) >> 32);
+}
+
 // Keep a just-loaded value in a register HERE.  hipcc sinks a load into the (conditional) block
 // that holds its only use, which turns "issue a batch of loads, then consume them" back into
 // load / s_waitcnt vmcnt(0) / use, one exposed HBM round trip per element.

@@ -41,6 +41,8 @@ struct SlParams {
     int32_t auto_reset;
     int32_t D;
     uint32_t magicN;
+    int32_t rs_hi;                  // random_start: draw in [0, rs_hi) on the device (0 = off)
+    unsigned long long rs_seed;
 };
 
 #define LF(fld) (*at(p.st.f64, (unsigned)(fld) * (unsigned)E + (unsigned)e))
@@ -155,7 +157,8 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
 
     if (RESET_ONLY) {                                                          // :134-165
         const bool sel = valid && (p.mask == nullptr || p.mask[e] != 0);
-        const int start = LI(FINENV_LI_NEXT_START);
+        const int start = p.rs_hi > 0 ? draw_start(p.rs_seed, e, LI(FINENV_LI_EPISODE) + 1, p.rs_hi)
+                                      : LI(FINENV_LI_NEXT_START);
         if (sel) {
             LI(FINENV_LI_START) = start;
             LI(FINENV_LI_DATE_INDEX) = start;
@@ -357,7 +360,8 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
         if (p.auto_reset) {                                                      // reset()
             wave_sync();
             if (done) {
-                const int ns = LI(FINENV_LI_NEXT_START);
+                const int ns = p.rs_hi > 0 ? draw_start(p.rs_seed, e, LI(FINENV_LI_EPISODE) + 1, p.rs_hi)
+                                           : LI(FINENV_LI_NEXT_START);
                 di = ns;
                 row_day = ns;
                 coh = c.initial_amount;
@@ -394,6 +398,8 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
 }  // namespace
 
 struct finenv_stoploss {
+    int32_t rs_hi;
+    unsigned long long rs_seed;
     int device;           // HIP device that owns the bound state block (-1 before bind)
     finenv_stoploss_config cfg;
     finenv_stoploss_panel panel;
@@ -428,6 +434,8 @@ SlParams sl_params(const finenv_stoploss *h)
     p.st = h->st;
     p.D = h->D;
     p.magicN = h->magicN;
+    p.rs_hi = h->rs_hi;
+    p.rs_seed = h->rs_seed;
     return p;
 }
 dim3 sl_grid(int E)
@@ -481,6 +489,14 @@ int finenv_stoploss_bind(finenv_stoploss *h, const finenv_stoploss_panel *panel,
     h->st = *st;
     h->device = finenv_host::pointer_device(st->f64);
     h->bound = 1;
+    return FINENV_OK;
+}
+
+int finenv_stoploss_set_random_start(finenv_stoploss *h, int32_t hi, uint64_t seed)
+{
+    if (!h || hi < 0 || hi > h->cfg.n_days) return FINENV_ERR_INVALID;
+    h->rs_hi = hi;
+    h->rs_seed = seed;
     return FINENV_OK;
 }
 

@@ -75,8 +75,7 @@ class VecCashPenaltyEnv:
         self.auto_reset = bool(auto_reset)
         self.observation_space = Box(-np.inf, np.inf, (panel.D,), np.float32)
         self.action_space = Box(-1, 1, (N,), np.float32)
-        self._gen = torch.Generator(device=self.device)
-        self._gen.manual_seed(seed)
+        self._seed, self._rs_on_device = int(seed) & (2 ** 63 - 1), False
         L = nat.lib()
         self._cfg = self._cfg_cls(
             E, N, Cc, T, int(discrete_actions), int(shares_increment),
@@ -135,9 +134,13 @@ class VecCashPenaltyEnv:
             np.broadcast_to(np.asarray(starts, np.int32), (self.num_envs,)).copy()))
 
     def _draw_starts(self):
-        import torch
-        hi = max(1, int(self.panel.T * 0.5))
-        self.state["next_start"].random_(0, hi, generator=self._gen)     # one in-place kernel
+        """random_start: resets draw their starting point on the device (set once; no host work
+        per step).  `set_next_start()` + random_start=False pins them for reproducible runs."""
+        if not self._rs_on_device:
+            hi = max(1, int(self.panel.T * 0.5))                                   # :134-138
+            nat.check(self._fn("set_random_start")(self._h, hi, int(self._seed)), self._h,
+                      "set_random_start", self._kind)
+            self._rs_on_device = True
 
     def reset(self, mask=None):
         import torch

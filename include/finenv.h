@@ -405,6 +405,11 @@ int  finenv_cashpenalty_bind(finenv_cashpenalty *h, const finenv_cashpenalty_pan
                              const finenv_cashpenalty_state *state);
 int  finenv_cashpenalty_reset(finenv_cashpenalty *h, const uint8_t *mask, float *obs_out,
                               void *stream);
+/* random_start (:134-138: `random.choice(range(int(len(dates) * 0.5)))`): with hi > 0 every reset
+ * (explicit or inside step) draws its starting point on the device, uniformly in [0, hi), from a
+ * counter-based generator keyed by (seed, env, episode) -- no host work per step; hi == 0 (default):
+ * resets take FINENV_KI_NEXT_START.  Not bit-reproducible against Python's `random` by construction. */
+int  finenv_cashpenalty_set_random_start(finenv_cashpenalty *h, int32_t hi, uint64_t seed);
 int  finenv_cashpenalty_step(finenv_cashpenalty *h, const float *actions, float *obs,
                              float *reward, uint8_t *done, float *term_obs, int32_t auto_reset,
                              void *stream);
@@ -466,6 +471,8 @@ int  finenv_stoploss_bind(finenv_stoploss *h, const finenv_stoploss_panel *panel
 /* reset(), :134-165 (mask NULL = all envs; starting points from FINENV_LI_NEXT_START) */
 int  finenv_stoploss_reset(finenv_stoploss *h, const uint8_t *mask, float *obs_out, void *stream);
 /* step(), :292-442 (+ DummyVecEnv auto-reset when auto_reset != 0) */
+/* as finenv_cashpenalty_set_random_start (:142-147) */
+int  finenv_stoploss_set_random_start(finenv_stoploss *h, int32_t hi, uint64_t seed);
 int  finenv_stoploss_step(finenv_stoploss *h, const float *actions, float *obs, float *reward,
                           uint8_t *done, float *term_obs, int32_t auto_reset, void *stream);
 

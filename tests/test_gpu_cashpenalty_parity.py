@@ -106,3 +106,39 @@ def test_cashpenalty_hip_matches_oracle_random_batch(cfg):
             np.testing.assert_array_equal(env.term_obs.cpu().numpy()[o_done],
                                           o_term[o_done].astype(np.float32))
     assert nd >= 2
+
+
+def test_random_start_is_drawn_on_device():
+    """random_start=True (:134-138): starting points drawn on the device, uniformly in
+    [0, int(T * 0.5)), per env and per episode, reproducible from the seed; no host work per step."""
+    _need_gpu()
+    from finrl_amd.vec_cashpenalty import CashPenaltyPanel, VecCashPenaltyEnv
+    rng = np.random.default_rng(1)
+    T, N, E = 40, 4, 4096
+    close = 50 * np.exp(np.cumsum(rng.normal(0, 0.01, (T, N)), axis=0))
+    panel = CashPenaltyPanel(close, rng.normal(0, 1, (T, N, 2)))
+    envs = [VecCashPenaltyEnv(panel, E, hmax=1000, random_start=True, seed=s) for s in (7, 7, 8)]
+    starts = []
+    for env in envs:
+        env.reset()
+        st = env.state_numpy()
+        assert (st["start"] == st["date_index"]).all()
+        assert st["start"].min() >= 0 and st["start"].max() < T // 2
+        starts.append(st["start"].copy())
+    np.testing.assert_array_equal(starts[0], starts[1])          # same seed, same draws
+    assert (starts[0] != starts[2]).mean() > 0.8                 # another seed, other draws
+    counts = np.bincount(starts[0], minlength=T // 2)
+    assert counts.min() > 0.6 * E / (T // 2) and counts.max() < 1.4 * E / (T // 2)   # ~uniform
+    env = envs[0]
+    zero = torch.zeros(E, N, device="cuda")
+    first = starts[0]
+    seen = np.zeros(E, bool)
+    for s in range(T):                                           # every env reaches the last date
+        _, _, done, _ = env.step(zero)
+        d = done.cpu().numpy().astype(bool)
+        st = env.state_numpy()
+        assert (st["start"][d] == st["date_index"][d]).all()     # auto-reset drew a fresh start
+        assert st["start"].max() < T // 2
+        seen |= d
+    assert seen.all()
+    assert (env.state_numpy()["start"] != first).mean() > 0.8    # new episode, new draw
