@@ -75,7 +75,9 @@ def cpu_baseline(close, tech, risk, budget_s=12.0):
     return dict(value=Ec * steps / dt, unit="env-steps/s", cores=1, kind="port",
                 sample=f"{Ec} envs x {steps} steps ({dt:.1f} s) of the same DOW30x8 workload, "
                        "oracle/stock_oracle.c single thread, obs included "
-                       f"(host has {os.cpu_count()} cores)")
+                       f"(host has {os.cpu_count()} cores; the reference itself -- Python/pandas, "
+                       "one core of the build container -- runs this env at ~153 env-steps/s, "
+                       "SURVEY.md section 6; it cannot travel to the GPU box)")
 
 
 def parity_sample(close, tech, risk, dev, n_envs=256, n_steps=300):
