@@ -184,9 +184,20 @@ def bench_portfolio(args, torch, dev):
         "config": {"workload": f"{E} vectorized StockPortfolioEnv, DOW30 x 8, T={T}",
                    "envs_per_gpu": E},
         "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                     "frac": ach / HBM_PEAK_GBS, "traffic": side_traffic("portfolio", E),
                      "kernel": "portfolio_step_kernel", "bytes_per_env_step": B,
                      "avg_launch_us": per * 1e6}}), flush=True)
+
+
+def side_traffic(kind, E):
+    """PMC-measured HBM bytes per launch of a sibling kernel (profiles/side_traffic.json), or None."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "side_traffic.json")))
+        if tj.get("envs_per_gpu") == E:
+            return tj["envs"][kind]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
 def bench_side(args, torch, dev, kind):
@@ -246,7 +257,7 @@ def bench_side(args, torch, dev, kind):
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{E} {name}", "envs_per_gpu": E},
         "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": kern,
+                     "frac": ach / HBM_PEAK_GBS, "traffic": side_traffic(kind, E), "kernel": kern,
                      "bytes_per_env_step": B, "avg_launch_us": per * 1e6}}), flush=True)
 
 
