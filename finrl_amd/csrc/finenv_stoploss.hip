@@ -191,32 +191,38 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
     const unsigned cb = (unsigned)(di * N);
     wave_sync();
 
-    // ---- pass 1: reward terms of the state as the previous step left it (:313 / :304) ---------
+    // ---- pass 1: reward terms of the state as the previous step left it (:313 / :304).  On every
+    // step but the last date these sums ride along in pass 2 (same assets, same order), which saves
+    // re-reading the holdings and previous-holdings books: the three-pass form moved 1.34x the
+    // algorithmic bytes (PMC, profiles/side_traffic.json).
     double slp_sum = 0.0, lpp_sum = 0.0, add = 0.0;
+    const double lt_old = logged_total, lc_old = logged_cash;
     // (every per-asset loop below runs in batches of kB assets with the batch's global loads issued
     //  first: a rolled loop exposes one HBM round trip per asset at one wave per SIMD)
-    for (int i0 = 0; i0 < N; i0 += kB) {
-        double hh[kB], ps[kB], ph[kB], cd[kB];
+    if (at_end) {
+        for (int i0 = 0; i0 < N; i0 += kB) {
+            double hh[kB], ps[kB], ph[kB], cd[kB];
 #pragma unroll
-        for (int j = 0; j < kB; ++j) {
-            const int i = min(i0 + j, N - 1);
-            hh[j] = LV(FINENV_LV_HOLDINGS, i);
-            ps[j] = LV(FINENV_LV_PROFIT_SELL_DIFF_AVG_BUY, i);
-            ph[j] = LV(FINENV_LV_PREV_HOLDINGS, i);
-            cd[j] = LV(FINENV_LV_CLOSING_DIFF_AVG_BUY, i);
-        }
+            for (int j = 0; j < kB; ++j) {
+                const int i = min(i0 + j, N - 1);
+                hh[j] = LV(FINENV_LV_HOLDINGS, i);
+                ps[j] = LV(FINENV_LV_PROFIT_SELL_DIFF_AVG_BUY, i);
+                ph[j] = LV(FINENV_LV_PREV_HOLDINGS, i);
+                cd[j] = LV(FINENV_LV_CLOSING_DIFF_AVG_BUY, i);
+            }
 #pragma unroll
-        for (int j = 0; j < kB; ++j) { pin(hh[j]); pin(ps[j]); pin(ph[j]); pin(cd[j]); }
+            for (int j = 0; j < kB; ++j) { pin(hh[j]); pin(ps[j]); pin(ph[j]); pin(cd[j]); }
 #pragma unroll
-        for (int j = 0; j < kB; ++j) {
-            if (i0 + j >= N) break;
-            sum_trades += fabs((double)row[i0 + j]);                             // :294
-            slp_sum += ph[j] * fmin(cd[j], 0.0);                                 // :262,:273-275
-            lpp_sum += hh[j] * fmin(ps[j], 0.0);                                 // :263-265,:278-280
-            add += hh[j] * fmax(ps[j], 0.0);                                     // :266-268,:283
+            for (int j = 0; j < kB; ++j) {
+                if (i0 + j >= N) break;
+                sum_trades += fabs((double)row[i0 + j]);                         // :294
+                slp_sum += ph[j] * fmin(cd[j], 0.0);                             // :262,:273-275
+                lpp_sum += hh[j] * fmin(ps[j], 0.0);                             // :263-265,:278-280
+                add += hh[j] * fmax(ps[j], 0.0);                                 // :266-268,:283
+            }
         }
     }
-    double reward = sl_reward(c, step, logged_total, logged_cash, slp_sum, lpp_sum, add);
+    double reward = at_end ? sl_reward(c, step, lt_old, lc_old, slp_sum, lpp_sum, add) : 0.0;  // :304
     bool done = at_end;
 
     // ---- pass 2: transactions (:320-357), proceeds / spend (:363-370) --------------------------
@@ -228,7 +234,7 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
     double coh_new = coh;
     if (!at_end) {
         for (int i0 = 0; i0 < N; i0 += kB) {
-            double hb[kB], clb[kB], ab[kB], pb[kB];
+            double hb[kB], clb[kB], ab[kB], pb[kB], pso[kB], cdo[kB];
 #pragma unroll
             for (int j = 0; j < kB; ++j) {
                 const int i = min(i0 + j, N - 1);
@@ -236,14 +242,22 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
                 clb[j] = *at(p.panel.close, cb + (unsigned)i);
                 ab[j] = LV(FINENV_LV_AVG_BUY_PRICE, i);
                 pb[j] = LV(FINENV_LV_PREV_HOLDINGS, i);
+                pso[j] = LV(FINENV_LV_PROFIT_SELL_DIFF_AVG_BUY, i);      // pass-1 terms (old books)
+                cdo[j] = LV(FINENV_LV_CLOSING_DIFF_AVG_BUY, i);
             }
 #pragma unroll
-            for (int j = 0; j < kB; ++j) { pin(hb[j]); pin(clb[j]); pin(ab[j]); pin(pb[j]); }
+            for (int j = 0; j < kB; ++j) {
+                pin(hb[j]); pin(clb[j]); pin(ab[j]); pin(pb[j]); pin(pso[j]); pin(cdo[j]);
+            }
 #pragma unroll
             for (int j = 0; j < kB; ++j) {
                 const int i = i0 + j;
                 if (i >= N) break;
                 const double h = hb[j], cl = clb[j], abp = ab[j];
+                sum_trades += fabs((double)row[i]);                              // :294
+                slp_sum += pb[j] * fmin(cdo[j], 0.0);                            // :262,:273-275
+                lpp_sum += h * fmin(pso[j], 0.0);                                // :263-265,:278-280
+                add += h * fmax(pso[j], 0.0);                                    // :266-268,:283
                 asset_value += h * cl;                                           // :311
                 const float a32 = row[i] * hmaxf;                                // :321 (float32)
                 double a = cl > 0.0 ? (double)a32 : 0.0;                         // :326
@@ -269,6 +283,7 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
                 spend += (tr > 0.0 ? tr : 0.0) * cl;                             // :368-369
             }
         }
+        reward = sl_reward(c, step, lt_old, lc_old, slp_sum, lpp_sum, add);      // :313 (stale log)
         logged_cash = coh;                                                       // :315-317
         logged_total = coh + asset_value;
         double costs = proceeds * c.sell_cost_pct;                               // :365
