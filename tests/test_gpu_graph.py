@@ -97,3 +97,48 @@ def test_stock_env_segment_in_graph_matches_eager():
         if rep == 1:
             assert int(bufs[0].dones.sum()) > 0                  # an episode boundary was crossed
         o0, o1 = last0, bufs[1].obs[n_steps].clone()
+
+
+def test_two_handles_on_two_streams_do_not_interfere():
+    """One handle per stream: two envs of different shapes (32-wide and 128-wide
+    kernels, dynamic-LDS opt-in included) stepped interleaved on two HIP streams give the same
+    results as stepping each alone."""
+    _need_gpu()
+    import bench
+    from finrl_amd import StockPanel
+    from finrl_amd.vec_env import VecStockTradingEnv
+    shapes = [(30, 3000), (100, 1000)]
+    gens = [torch.Generator(device="cuda") for _ in shapes]
+    for g in gens:
+        g.manual_seed(3)
+    panels = []
+    for N, E in shapes:
+        c, t, r = bench.synth_panel(N=N)
+        panels.append(StockPanel(c[:60], t[:60], r[:60]))
+    acts = [[torch.rand(E, N, generator=g, device="cuda") * 2 - 1 for _ in range(70)]
+            for (N, E), g in zip(shapes, gens)]
+    torch.cuda.synchronize()
+
+    def make():
+        return [VecStockTradingEnv(p, E, **bench.ENV_KW) for p, (N, E) in zip(panels, shapes)]
+
+    serial = make()
+    outs_serial = []
+    for env, a in zip(serial, acts):
+        env.reset()
+        for x in a:
+            env.step(x)
+        outs_serial.append({k: v.clone() for k, v in env.state.items()})
+    streams = [torch.cuda.Stream() for _ in shapes]
+    inter = make()
+    for env, s in zip(inter, streams):
+        with torch.cuda.stream(s):
+            env.reset()
+    for t in range(70):
+        for env, s, a in zip(inter, streams, acts):
+            with torch.cuda.stream(s):
+                env.step(a[t])
+    torch.cuda.synchronize()
+    for env, ref in zip(inter, outs_serial):
+        for k in ref:
+            assert torch.equal(env.state[k], ref[k]), k
