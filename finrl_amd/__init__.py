@@ -12,9 +12,20 @@ from .panel import StockPanel  # noqa: F401
 __version__ = "0.1.0"
 
 
+_LAZY = {      # name -> module; lazy because these need the native library
+    "VecStockTradingEnv": "vec_env", "SB3VecEnvAdapter": "vec_env", "SingleEnvVecAdapter": "vec_env",
+    "VecStockPortfolioEnv": "vec_portfolio", "VecCryptoEnv": "vec_crypto",
+    "VecStockTradingEnvNP": "vec_stocknp", "VecCashPenaltyEnv": "vec_cashpenalty",
+    "VecStopLossEnv": "vec_cashpenalty", "CashPenaltyPanel": "vec_cashpenalty",
+    "RolloutBuffer": "rollout", "GraphedSegment": "graph",
+}
+
+
 def __getattr__(name):
-    # Lazy: these need the native library.
-    if name in ("VecStockTradingEnv", "SB3VecEnvAdapter"):
-        from . import vec_env
-        return getattr(vec_env, name)
+    if name in _LAZY:
+        import importlib
+        return getattr(importlib.import_module(f".{_LAZY[name]}", __name__), name)
+    if name == "PortfolioPanel":
+        from .panel import PortfolioPanel
+        return PortfolioPanel
     raise AttributeError(name)
