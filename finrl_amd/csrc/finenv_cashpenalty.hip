@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(kWave *kWaves) cashpenalty_kernel(const CpPara
 #pragma unroll
             for (int j = 0; j < kB; ++j) {
                 const int i = i0 + j;
-                if (i >= N) break;
+                if (i >= N) continue;          // (continue, not break: keeps the loop fully unrollable)
                 const double h = hb[j], cl = clb[j];
                 asset_value += h * cl;                                           // np.dot, :310
                 const float a32 = row[i] * hmaxf;                                // :257 (float32)
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(kWave *kWaves) cashpenalty_kernel(const CpPara
 #pragma unroll
             for (int j = 0; j < kB; ++j) {
                 const int i = i0 + j;
-                if (i >= N) break;
+                if (i >= N) continue;          // (continue, not break: keeps the loop fully unrollable)
                 const double tr = trl[i * kWave + lane];
                 const double hn = hb[j] + ((tr > 0.0 && !keep_buys) ? 0.0 : tr); // :352
                 if (valid) KH(i) = hn;

@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
             for (int j = 0; j < kB; ++j) { pin(hh[j]); pin(ps[j]); pin(ph[j]); pin(cd[j]); }
 #pragma unroll
             for (int j = 0; j < kB; ++j) {
-                if (i0 + j >= N) break;
+                if (i0 + j >= N) continue;
                 sum_trades += fabs((double)row[i0 + j]);                         // :294
                 slp_sum += ph[j] * fmin(cd[j], 0.0);                             // :262,:273-275
                 lpp_sum += hh[j] * fmin(ps[j], 0.0);                             // :263-265,:278-280
@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
 #pragma unroll
             for (int j = 0; j < kB; ++j) {
                 const int i = i0 + j;
-                if (i >= N) break;
+                if (i >= N) continue;          // (continue, not break: keeps the loop fully unrollable)
                 const double h = hb[j], cl = clb[j], abp = ab[j];
                 sum_trades += fabs((double)row[i]);                              // :294
                 slp_sum += pb[j] * fmin(cdo[j], 0.0);                            // :262,:273-275
@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
 #pragma unroll
             for (int j = 0; j < kB; ++j) {
                 const int i = i0 + j;
-                if (i >= N) break;
+                if (i >= N) continue;          // (continue, not break: keeps the loop fully unrollable)
                 const double tr0 = trl[i * kWave + lane];
                 const double cl = clb[j], h = hb[j];
                 double abp = ab[j], nb = nbb[j];
