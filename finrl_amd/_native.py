@@ -11,6 +11,10 @@ LIB_PATH = os.environ.get("FINENV_LIB") or os.path.join(_HERE, "lib", "libfinenv
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 FINENV_OK = 0
+ABI_VERSION = 3            # include/finenv.h FINENV_ABI_VERSION
+AUDIT_HEAD = 4             # FINENV_AUDIT_HEAD: begin cash, asset value, reward, flags
+AUDIT_F_LAST_DATE, AUDIT_F_CASH_SHORTAGE, AUDIT_F_TURBULENCE, AUDIT_F_STOP_LOSS, \
+    AUDIT_F_LOW_PROFIT, AUDIT_F_HIGH_PROFIT = 1, 2, 4, 8, 16, 32
 
 
 class NativeLibraryError(ImportError):
@@ -246,7 +250,9 @@ def lib():
                                              C.c_int32, C.c_void_p]
     L.finenv_cashpenalty_set_random_start.argtypes = [C.c_void_p, C.c_int32, C.c_uint64]
     L.finenv_stoploss_set_random_start.argtypes = [C.c_void_p, C.c_int32, C.c_uint64]
-    if L.finenv_abi_version() != 2:
+    L.finenv_cashpenalty_set_audit.argtypes = [C.c_void_p, C.c_void_p]
+    L.finenv_stoploss_set_audit.argtypes = [C.c_void_p, C.c_void_p]
+    if L.finenv_abi_version() != ABI_VERSION:
         raise NativeLibraryError("libfinenv.so ABI version mismatch; rebuild (make -C finrl_amd/csrc)")
     L.finenv_struct_size.argtypes = [C.c_int]
     for which, cls in enumerate((StockConfig, StockPanelPtrs, StockStatePtrs, PortfolioConfig,

@@ -41,6 +41,7 @@ struct CpParams {
     uint32_t magicN;
     int32_t rs_hi;                  // random_start: draw in [0, rs_hi) on the device (0 = off)
     unsigned long long rs_seed;
+    double *audit;                  // optional [E][FINENV_AUDIT_HEAD + N] per-step log row, or NULL
 };
 
 #define KF(fld) (*at(p.st.f64, (unsigned)(fld) * (unsigned)E + (unsigned)e))
@@ -248,6 +249,19 @@ __global__ void __launch_bounds__(kWave *kWaves) cashpenalty_kernel(const CpPara
         }
         coh_new = coh1 - spend - costs;                                          // :351
     }
+    if (p.audit != nullptr && valid) {      // harness log row (account_information / transaction_memory)
+        double *au = p.audit + (size_t)e * (size_t)(FINENV_AUDIT_HEAD + N);
+        au[FINENV_AUDIT_BEGIN_CASH] = coh;                                       // :312
+        au[FINENV_AUDIT_ASSET_VALUE] = asset_value;                              // :313
+        au[FINENV_AUDIT_REWARD] = reward;                                        // :317
+        au[FINENV_AUDIT_FLAGS] = (double)((at_end ? FINENV_AUDIT_F_LAST_DATE : 0) |
+            ((!at_end && (done || !keep_buys)) ? FINENV_AUDIT_F_CASH_SHORTAGE : 0) |
+            ((!at_end && turbulent) ? FINENV_AUDIT_F_TURBULENCE : 0));
+        for (int i = 0; i < N; ++i) {
+            const double tr = at_end ? 0.0 : trl[i * kWave + lane];
+            au[FINENV_AUDIT_HEAD + i] = (tr > 0.0 && !keep_buys) ? 0.0 : tr;     // :336 / :345
+        }
+    }
     const bool advance = !done;
     if (advance) {
         coh = coh_new;
@@ -331,6 +345,7 @@ __global__ void __launch_bounds__(kWave *kWaves) cashpenalty_kernel(const CpPara
 struct finenv_cashpenalty {
     int32_t rs_hi;
     unsigned long long rs_seed;
+    double *audit;
     int device;           // HIP device that owns the bound state block (-1 before bind)
     finenv_cashpenalty_config cfg;
     finenv_cashpenalty_panel panel;
@@ -367,6 +382,7 @@ CpParams kp_params(const finenv_cashpenalty *h)
     p.magicN = h->magicN;
     p.rs_hi = h->rs_hi;
     p.rs_seed = h->rs_seed;
+    p.audit = h->audit;
     return p;
 }
 dim3 kp_grid(int E)
@@ -428,6 +444,13 @@ int finenv_cashpenalty_set_random_start(finenv_cashpenalty *h, int32_t hi, uint6
     if (!h || hi < 0 || hi > h->cfg.n_days) return FINENV_ERR_INVALID;
     h->rs_hi = hi;
     h->rs_seed = seed;
+    return FINENV_OK;
+}
+
+int finenv_cashpenalty_set_audit(finenv_cashpenalty *h, double *audit)
+{
+    if (!h) return FINENV_ERR_INVALID;
+    h->audit = audit;
     return FINENV_OK;
 }
 

@@ -43,6 +43,7 @@ struct SlParams {
     uint32_t magicN;
     int32_t rs_hi;                  // random_start: draw in [0, rs_hi) on the device (0 = off)
     unsigned long long rs_seed;
+    double *audit;                  // optional [E][FINENV_AUDIT_HEAD + N] per-step log row, or NULL
 };
 
 #define LF(fld) (*at(p.st.f64, (unsigned)(fld) * (unsigned)E + (unsigned)e))
@@ -232,6 +233,8 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
     double asset_value = 0.0, proceeds = 0.0, spend = 0.0, slp_new = 0.0;
     bool keep_buys = true;
     double coh_new = coh;
+    const double coh_begin = coh;
+    int audit_flags = at_end ? FINENV_AUDIT_F_LAST_DATE : 0;
     if (!at_end) {
         for (int i0 = 0; i0 < N; i0 += kB) {
             double hb[kB], clb[kB], ab[kB], pb[kB], pso[kB], cdo[kB];
@@ -278,6 +281,7 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
                 if (valid) LV(FINENV_LV_CLOSING_DIFF_AVG_BUY, i) = cd;
                 slp_new += pb[j] * fmin(cd, 0.0);
                 tr = (stop_armed && cd < 0.0) ? -h : tr;                         // :353-357
+                audit_flags |= (stop_armed && cd < 0.0) ? FINENV_AUDIT_F_STOP_LOSS : 0;   // :359-360
                 trl[i * kWave + lane] = tr;
                 proceeds += (tr < 0.0 ? -tr : 0.0) * cl;                         // :363-364
                 spend += (tr > 0.0 ? tr : 0.0) * cl;                             // :368-369
@@ -289,7 +293,9 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
         double costs = proceeds * c.sell_cost_pct;                               // :365
         const double coh1 = coh + proceeds;                                      // :366
         costs += spend * c.buy_cost_pct;                                         // :370
+        audit_flags |= turbulent ? FINENV_AUDIT_F_TURBULENCE : 0;
         if (spend + costs > coh1) {                                              // :372
+            audit_flags |= FINENV_AUDIT_F_CASH_SHORTAGE;
             if (c.patient) {                                                     // :373-378
                 keep_buys = false;
                 spend = 0.0;
@@ -332,6 +338,8 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
                 const double scp = sold ? cl : 0.0;                              // :388-390
                 const bool profit = scp - abp > 0.0;                             // :391-393
                 const double ps = profit ? cl - (c.min_profit_penalty * abp) : 0.0;  // :395-399
+                audit_flags |= ps < 0.0 ? FINENV_AUDIT_F_LOW_PROFIT                   // :401-405
+                                        : (ps > 0.0 ? FINENV_AUDIT_F_HIGH_PROFIT : 0);
                 ntr += tr != 0.0 ? 1.0 : 0.0;                                    // :411
                 const double hu = h + tr;                                        // :415
                 nb += bought ? 1.0 : 0.0;                                        // :419
@@ -355,6 +363,17 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
         if (c.use_turbulence) turb = *at(p.panel.turb, (unsigned)di);            // :431-434
     } else {
         for (int i = 0; i < N; ++i) row[1 + i] = (float)LV(FINENV_LV_HOLDINGS, i);
+    }
+    if (p.audit != nullptr && valid) {      // harness log row (account_information / transaction_memory)
+        double *au = p.audit + (size_t)e * (size_t)(FINENV_AUDIT_HEAD + N);
+        au[FINENV_AUDIT_BEGIN_CASH] = coh_begin;                                 // :307
+        au[FINENV_AUDIT_ASSET_VALUE] = asset_value;                              // :311
+        au[FINENV_AUDIT_REWARD] = reward;
+        au[FINENV_AUDIT_FLAGS] = (double)audit_flags;
+        for (int i = 0; i < N; ++i) {
+            const double tr = at_end ? 0.0 : trl[i * kWave + lane];
+            au[FINENV_AUDIT_HEAD + i] = (tr > 0.0 && !keep_buys) ? 0.0 : tr;     // :376 / :385
+        }
     }
     row[0] = (float)coh;
     if (valid) {
@@ -415,6 +434,7 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
 struct finenv_stoploss {
     int32_t rs_hi;
     unsigned long long rs_seed;
+    double *audit;
     int device;           // HIP device that owns the bound state block (-1 before bind)
     finenv_stoploss_config cfg;
     finenv_stoploss_panel panel;
@@ -451,6 +471,7 @@ SlParams sl_params(const finenv_stoploss *h)
     p.magicN = h->magicN;
     p.rs_hi = h->rs_hi;
     p.rs_seed = h->rs_seed;
+    p.audit = h->audit;
     return p;
 }
 dim3 sl_grid(int E)
@@ -512,6 +533,13 @@ int finenv_stoploss_set_random_start(finenv_stoploss *h, int32_t hi, uint64_t se
     if (!h || hi < 0 || hi > h->cfg.n_days) return FINENV_ERR_INVALID;
     h->rs_hi = hi;
     h->rs_seed = seed;
+    return FINENV_OK;
+}
+
+int finenv_stoploss_set_audit(finenv_stoploss *h, double *audit)
+{
+    if (!h) return FINENV_ERR_INVALID;
+    h->audit = audit;
     return FINENV_OK;
 }
 

@@ -19,7 +19,7 @@ import numpy as np
 
 from ...panel import StockPanel
 from ...spaces import Box
-from ...vec_env import SB3VecEnvAdapter, VecStockTradingEnv
+from ...vec_env import SingleEnvVecAdapter, VecStockTradingEnv
 
 
 class StockTradingEnv:
@@ -114,9 +114,26 @@ class StockTradingEnv:
         return self.state[0] + sum(p * h)
 
     # ------------------------------------------------------------------ gym protocol
+    def _device_actions(self, actions):
+        """float32 actions go to the kernel as they are (it scales and truncates in float32 like
+        :304-305 does for SB3's float32 arrays).  Any other dtype (float64 arrays, Python lists) is
+        scaled HERE in the caller's dtype -- exactly the reference's `(actions * hmax).astype(int)`
+        -- and the integer share counts are handed over as float32 values k' = (k +- 0.5) / hmax
+        that the kernel's float32 multiply-truncate maps back to k exactly (checked below)."""
+        a = np.asarray(actions)
+        if a.dtype == np.float32:
+            return a.reshape(1, -1)
+        k = (a * self.hmax).astype(int).reshape(1, -1)                          # :304-305
+        enc = ((k + 0.5 * np.sign(k)) / self.hmax).astype(np.float32) if self.hmax else \
+            np.zeros(k.shape, np.float32)
+        if not np.array_equal((enc * np.float32(self.hmax)).astype(np.int64), k):
+            raise ValueError("non-float32 actions: scaled share counts exceed the exactly "
+                             "representable range; pass float32 actions")
+        return enc
+
     def step(self, actions):
         torch = self._torch
-        a = torch.as_tensor(np.asarray(actions, dtype=np.float32).reshape(1, -1))
+        a = torch.as_tensor(np.ascontiguousarray(self._device_actions(actions)))
         was_terminal_day = self.day >= self.panel.T - 1
         _, rew, done, _ = self._vec.step(a.to(self._vec.device))
         self.terminal = bool(done.cpu().numpy()[0])
@@ -230,14 +247,15 @@ class StockTradingEnv:
 
     def get_sb_env(self):
         """(vec_env, first_obs) as the reference returns from DummyVecEnv([lambda: self]), :549-552.
-        With stable-baselines3 installed its DummyVecEnv wraps this object; otherwise the
-        built-in VecEnv-shaped adapter drives the same device batch."""
+        With stable-baselines3 installed its DummyVecEnv wraps this object; otherwise the built-in
+        DummyVecEnv-shaped adapter wraps it -- either way every step goes through this facade, so
+        ``asset_memory`` / ``actions_memory`` keep filling and ``env_method("save_asset_memory")``
+        (agents/stablebaselines3/models.py:120-121) finds its target."""
         try:
             from stable_baselines3.common.vec_env import DummyVecEnv
             e = DummyVecEnv([lambda: self])
         except ImportError:
-            self._vec.auto_reset = True
-            e = SB3VecEnvAdapter(self._vec)
+            e = SingleEnvVecAdapter(self)
         obs = e.reset()
         return e, obs
 

@@ -5,6 +5,7 @@
 one HIP launch per step through the C ABI (finenv_stoploss_*)."""
 from __future__ import annotations
 
+from ... import _native as nat
 from ...vec_cashpenalty import VecStopLossEnv
 from .env_stocktrading_cashpenalty import StockTradingEnvCashpenalty
 
@@ -20,12 +21,31 @@ class StockTradingEnvStopLoss(StockTradingEnvCashpenalty):
                  cache_indicator_data=True, cash_penalty_proportion=0.1, random_start=True,
                  patient=False, currency="$", device="cuda"):
         self.stoploss_penalty = stoploss_penalty
+        self.profit_loss_ratio = profit_loss_ratio
         self.min_profit_penalty = 1 + profit_loss_ratio * (1 - stoploss_penalty)    # :101
         super().__init__(df, buy_cost_pct, sell_cost_pct, date_col_name, hmax, discrete_actions,
                          shares_increment, turbulence_threshold, print_verbosity, initial_amount,
                          daily_information_cols, cache_indicator_data, cash_penalty_proportion,
                          random_start, patient, currency, device,
                          stoploss_penalty=stoploss_penalty, profit_loss_ratio=profit_loss_ratio)
+
+    def _extra_ctor(self):
+        return dict(stoploss_penalty=self.stoploss_penalty, profit_loss_ratio=self.profit_loss_ratio)
+
+    def _record_action(self, actions, closings):
+        self.actions_memory.append((actions * self.hmax) * closings)                # :321-324
+
+    def _reasons_before_shortage(self, flags):
+        return [("TURBULENCE", flags & nat.AUDIT_F_TURBULENCE),                     # :327-331
+                ("STOP LOSS", flags & nat.AUDIT_F_STOP_LOSS)]                       # :359-360
+
+    def _reasons_after_trades(self, flags):                                         # :401-405
+        if flags & nat.AUDIT_F_LOW_PROFIT:
+            return [("LOW PROFIT", True)]
+        return [("HIGH PROFIT", flags & nat.AUDIT_F_HIGH_PROFIT)]
+
+    def _record_extra(self, logger):                                                # :195-198
+        logger.record("environment/actual_num_trades", self.actual_num_trades)
 
     def _sync(self):
         state = super()._sync()

@@ -107,6 +107,7 @@ class VecCashPenaltyEnv:
         self.reward = torch.zeros(E, dtype=torch.float32, device=dev)
         self.done = torch.zeros(E, dtype=torch.uint8, device=dev)
         self.term_obs = None
+        self.audit = None
 
     def _stream(self):
         import torch
@@ -125,6 +126,18 @@ class VecCashPenaltyEnv:
         if self.term_obs is None:
             self.term_obs = torch.zeros_like(self.obs)
         return self.term_obs
+
+    def enable_audit(self):
+        """Per-step harness log rows [E, AUDIT_HEAD + N] f64 (begin cash, asset value, reward,
+        reason flags, applied transactions): what the single-env facade appends to the reference's
+        account_information / transaction_memory lists.  Off by default (no extra traffic)."""
+        import torch
+        if getattr(self, "audit", None) is None:
+            self.audit = torch.zeros(self.num_envs, nat.AUDIT_HEAD + self.action_dim,
+                                     dtype=torch.float64, device=self.device)
+            nat.check(self._fn("set_audit")(self._h, C.c_void_p(self.audit.data_ptr())), self._h,
+                      "set_audit", self._kind)
+        return self.audit
 
     def set_next_start(self, starts):
         """Starting points the next reset of each env will use (the reference draws

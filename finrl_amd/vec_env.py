@@ -278,25 +278,40 @@ class SB3VecEnvAdapter:
         obs = self.env.observe() if hasattr(self.env, "observe") else self.env.obs
         return obs.cpu().numpy()
 
+    def _indices(self, indices):
+        """SB3 ``VecEnv._get_indices``: None -> all envs, int -> [int], else the iterable."""
+        if indices is None:
+            return list(range(self.num_envs))
+        if isinstance(indices, (int, np.integer)):
+            return [int(indices)]
+        return [int(i) for i in indices]
+
     def env_is_wrapped(self, wrapper_class, indices=None):
-        return [False] * self.num_envs
+        return [False] * len(self._indices(indices))
 
-    def get_attr(self, name, indices=None):
-        v = getattr(self.env, name)
-        return [v] * self.num_envs
+    def get_attr(self, attr_name, indices=None):
+        v = getattr(self.env, attr_name)
+        return [v] * len(self._indices(indices))
 
-    def set_attr(self, name, value, indices=None):
-        setattr(self.env, name, value)
+    def set_attr(self, attr_name, value, indices=None):
+        setattr(self.env, attr_name, value)
 
-    def env_method(self, name, *args, indices=None, **kwargs):
-        r = getattr(self.env, name)(*args, **kwargs)
-        return [r] * self.num_envs
+    def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
+        """SB3's public signature (the reference calls ``env_method(method_name=...)``,
+        agents/stablebaselines3/models.py:120-121).  The batch is one object, so the method
+        runs once and its result is repeated per selected env."""
+        r = getattr(self.env, method_name)(*method_args, **method_kwargs)
+        return [r] * len(self._indices(indices))
 
 
 class SingleEnvVecAdapter:
     """``DummyVecEnv([lambda: env])``-shaped wrapper around one of the single-env facades
-    (what the reference's ``get_sb_env`` returns): numpy in / out, auto-reset with
-    ``infos[0]["terminal_observation"]``."""
+    (what the reference's ``get_sb_env`` returns, env_stocktrading.py:549-552): SB3's documented
+    VecEnv behaviour -- observation / reward buffers in the spaces' dtype (float32), auto-reset
+    on done with ``infos[0]["terminal_observation"]``, ``env_method(method_name, ...)``,
+    ``get_attr / set_attr(..., indices)``, ``seed``, ``env_is_wrapped``.  SB3 is not vendored
+    in the reference (setup.py:34-36), so this boundary is parity unpinned upstream; the tests
+    drive it with the reference's own caller loop (agents/stablebaselines3/models.py:110-129)."""
 
     def __init__(self, env):
         self.env = env
@@ -305,9 +320,14 @@ class SingleEnvVecAdapter:
         self.observation_space = env.observation_space
         self.action_space = env.action_space
         self._actions = None
+        self.render_mode = None
+        self._obs_dtype = np.dtype(getattr(env.observation_space, "dtype", np.float32))
+
+    def _obs(self, obs):
+        return np.asarray(obs, dtype=self._obs_dtype)[None].copy()
 
     def reset(self):
-        return np.asarray(self.env.reset())[None]
+        return self._obs(self.env.reset())
 
     def step_async(self, actions):
         self._actions = np.asarray(actions)
@@ -316,23 +336,45 @@ class SingleEnvVecAdapter:
         obs, rew, done, info = self.env.step(self._actions[0])
         info = dict(info) if isinstance(info, dict) else {}
         if done:
-            info["terminal_observation"] = np.asarray(obs)
+            info["terminal_observation"] = np.asarray(obs, dtype=self._obs_dtype)
             obs = self.env.reset()
-        return (np.asarray(obs)[None], np.asarray([rew], dtype=np.float32),
-                np.asarray([done]), [info])
+        return (self._obs(obs), np.asarray([rew], dtype=np.float32),
+                np.asarray([done], dtype=bool), [info])
 
     def step(self, actions):
         self.step_async(actions)
         return self.step_wait()
 
-    def env_method(self, name, *a, **k):
-        return [getattr(self.env, name)(*a, **k)]
+    def _indices(self, indices):
+        if indices is None:
+            return [0]
+        if isinstance(indices, (int, np.integer)):
+            indices = [indices]
+        idx = [int(i) for i in indices]
+        if any(i != 0 for i in idx):
+            raise IndexError(f"indices {idx}: this VecEnv holds one env")
+        return idx
 
-    def get_attr(self, name, indices=None):
-        return [getattr(self.env, name)]
+    def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
+        return [getattr(self.env, method_name)(*method_args, **method_kwargs)
+                for _ in self._indices(indices)]
 
-    def set_attr(self, name, value, indices=None):
-        setattr(self.env, name, value)
+    def get_attr(self, attr_name, indices=None):
+        return [getattr(self.env, attr_name) for _ in self._indices(indices)]
+
+    def set_attr(self, attr_name, value, indices=None):
+        for _ in self._indices(indices):
+            setattr(self.env, attr_name, value)
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False for _ in self._indices(indices)]
+
+    def seed(self, seed=None):
+        fn = getattr(self.env, "seed", None) or getattr(self.env, "_seed", None)
+        return [fn(seed) if fn is not None else None]
+
+    def render(self, mode="human"):
+        return self.env.render(mode) if hasattr(self.env, "render") else None
 
     def close(self):
         pass

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FINENV_ABI_VERSION 2
+#define FINENV_ABI_VERSION 3
 
 enum {
     FINENV_OK = 0,
@@ -413,6 +413,18 @@ int  finenv_cashpenalty_set_random_start(finenv_cashpenalty *h, int32_t hi, uint
 int  finenv_cashpenalty_step(finenv_cashpenalty *h, const float *actions, float *obs,
                              float *reward, uint8_t *done, float *term_obs, int32_t auto_reset,
                              void *stream);
+/* Harness log (the reference's account_information / transaction_memory lists, :149-154, :345-347,
+ * read back by save_asset_memory / save_action_memory :382-409): when `audit` is non-NULL every
+ * step writes one f64 row [FINENV_AUDIT_HEAD + N] per env:
+ *   begin cash (:307/:312), asset value (:310), reward in f64 (:317), reason flags, then the N
+ *   transactions that were (or, on a cash-shortage terminal step, would have been) applied.
+ * Meant for the single-env facades (back-tests); NULL (default) = no log, no extra traffic. */
+enum { FINENV_AUDIT_BEGIN_CASH = 0, FINENV_AUDIT_ASSET_VALUE, FINENV_AUDIT_REWARD,
+       FINENV_AUDIT_FLAGS, FINENV_AUDIT_HEAD };
+enum { FINENV_AUDIT_F_LAST_DATE = 1, FINENV_AUDIT_F_CASH_SHORTAGE = 2,
+       FINENV_AUDIT_F_TURBULENCE = 4, FINENV_AUDIT_F_STOP_LOSS = 8,
+       FINENV_AUDIT_F_LOW_PROFIT = 16, FINENV_AUDIT_F_HIGH_PROFIT = 32 };
+int  finenv_cashpenalty_set_audit(finenv_cashpenalty *h, double *audit /* [E][HEAD+N] or NULL */);
 
 /* =====================================================================================
  * StockTradingEnvStopLoss
@@ -475,6 +487,9 @@ int  finenv_stoploss_reset(finenv_stoploss *h, const uint8_t *mask, float *obs_o
 int  finenv_stoploss_set_random_start(finenv_stoploss *h, int32_t hi, uint64_t seed);
 int  finenv_stoploss_step(finenv_stoploss *h, const float *actions, float *obs, float *reward,
                           uint8_t *done, float *term_obs, int32_t auto_reset, void *stream);
+/* as finenv_cashpenalty_set_audit; flags additionally carry STOP_LOSS (:359-360) and
+ * LOW_PROFIT / HIGH_PROFIT (:401-405), the reasons the reference logs for this env */
+int  finenv_stoploss_set_audit(finenv_stoploss *h, double *audit /* [E][HEAD+N] or NULL */);
 
 /* =====================================================================================
  * Risk precompute that feeds the panels.  Stateless; all buffers are

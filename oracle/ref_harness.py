@@ -89,8 +89,9 @@ class _DummyVecEnv:
         self.step_async(actions)
         return self.step_wait()
 
-    def env_method(self, name, *a, **k):
-        return [getattr(e, name)(*a, **k) for e in self.envs]
+    def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
+        # SB3's public signature; the reference calls it with method_name= (models.py:120-121)
+        return [getattr(e, method_name)(*method_args, **method_kwargs) for e in self.envs]
 
     def close(self):
         pass

@@ -709,13 +709,204 @@ RISKPRE_SCENARIOS = {
 }
 
 
+# ----------------------------------------------------------------- harness (caller loops)
+def _df_columns(df):
+    """DataFrame -> plain arrays (object columns holding arrays are stacked)."""
+    out = {}
+    for c in df.columns:
+        v = df[c].tolist()
+        if len(v) and isinstance(v[0], (np.ndarray, list)):
+            out[c] = np.stack([np.asarray(x, np.float64) for x in v])
+        elif len(v) and isinstance(v[0], str):
+            out[c] = np.asarray(v)
+        else:
+            out[c] = np.asarray(v, np.float64)
+    return out
+
+
+def run_harness(name, *, kind, seed, T, N, K=8, **kw):
+    """The reference's caller loops (tests/harness_loops.py restates them) run against the
+    UNMODIFIED reference envs behind the DummyVecEnv stand-in of oracle/ref_harness.py:
+      kind = sb3_stock        DRL_prediction over env_stocktrading.StockTradingEnv (O-stable)
+      kind = sb3_cashpenalty  DRL_prediction over StockTradingEnvCashpenalty
+      kind = sb3_stoploss     DRL_prediction over StockTradingEnvStopLoss
+      kind = erl_stocknp      ElegantRL prediction loop over env_stocktrading_np.StockTradingEnv
+    Stores the inputs and what the loops returned (DataFrame columns as arrays, printed text)."""
+    import pandas as pd
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import harness_loops as hl
+    rng = np.random.default_rng(seed + 9000)
+    base = rng.uniform(-1, 1, (T + 3, N)).astype(np.float32)
+    printed = io.StringIO()
+    out = dict(base=base, meta=np.array([f"kind={kind}", f"seed={seed}", f"numpy={np.__version__}",
+                                         f"pandas={pd.__version__}"]))
+    if kind == "sb3_stock":
+        mod = rh.stable_argsort_patch(rh.load_stocktrading())
+        thr = kw.get("turbulence_threshold")
+        close, tech, risk = synth_panel(seed, T, N, K, flag_frac=kw.get("flag_frac", 0.0))
+        names = [f"ind{k}" for k in range(K)]
+        df = rh.make_stock_frame(close, tech, risk, names, risk_col="turbulence")
+        ekw = dict(hmax=kw.get("hmax", 100), initial_amount=kw.get("initial_amount", 1_000_000),
+                   buy_cost_pct=1e-3, sell_cost_pct=1e-3, reward_scaling=1e-4)
+        with contextlib.redirect_stdout(printed):
+            env = mod.StockTradingEnv(df=df, stock_dim=N, num_stock_shares=[0] * N,
+                                      state_space=1 + 2 * N + K * N, action_space=N,
+                                      tech_indicator_list=names, turbulence_threshold=thr,
+                                      risk_indicator_col="turbulence", print_verbosity=1, **ekw)
+            model = hl.ScriptedModel(base, 1 + np.arange(N))           # the close columns
+            acct, acts = hl.drl_prediction(model, env)
+        out.update(close=close, tech=tech, risk=risk,
+                   cfg_int=np.array([T, N, K, ekw["hmax"], int(thr is not None)], np.int64),
+                   cfg_float=np.array([ekw["initial_amount"], 1e-3, 1e-3, 1e-4,
+                                       thr if thr is not None else 0.0]),
+                   account_date=np.asarray(acct["date"].tolist()),
+                   account_value=acct["account_value"].to_numpy(np.float64),
+                   actions=acts.to_numpy(np.int64), action_date=np.asarray(acts.index.tolist()),
+                   action_columns=np.asarray(acts.columns.tolist()),
+                   action_index_name=np.array(str(acts.index.name)))
+    elif kind in ("sb3_cashpenalty", "sb3_stoploss"):
+        cols = list(kw.get("cols", ("open", "close", "high", "low", "volume")))
+        sigma = kw.get("sigma", 0.01)
+        close = 50 * np.exp(np.cumsum(rng.normal(0, sigma, (T, N)), axis=0))
+        data = {"open": close * rng.uniform(0.99, 1.01, (T, N)), "close": close,
+                "high": close * 1.01, "low": close * 0.99,
+                "volume": rng.integers(1e5, 1e6, (T, N)).astype(np.float64)}
+        turb = np.abs(rng.normal(0, 30, T))
+        dates = [f"2020-{1 + t // 28:02d}-{1 + t % 28:02d}" for t in range(T)]
+        frame = {"date": np.repeat(dates, N), "tic": np.tile([f"TIC{i:03d}" for i in range(N)], T)}
+        for c in dict.fromkeys(cols + ["close"]):
+            frame[c] = data[c].reshape(-1)
+        frame["turbulence"] = np.repeat(turb, N)
+        df = pd.DataFrame(frame)
+        ekw = dict(buy_cost_pct=3e-3, sell_cost_pct=3e-3, hmax=kw.get("hmax", 20_000),
+                   discrete_actions=kw.get("discrete_actions", False),
+                   shares_increment=kw.get("shares_increment", 1),
+                   turbulence_threshold=kw.get("turbulence_threshold"),
+                   print_verbosity=kw.get("print_verbosity", 5),
+                   initial_amount=kw.get("initial_amount", 1e6), daily_information_cols=cols,
+                   cash_penalty_proportion=0.1, random_start=False,
+                   patient=kw.get("patient", False))
+        if kind == "sb3_cashpenalty":
+            mod = _fresh_cashpenalty()
+            cls = mod.StockTradingEnvCashpenalty
+        else:
+            rh.install()
+            import importlib
+            sys.modules.pop("finrl.meta.env_stock_trading.env_stocktrading_stoploss", None)
+            mod = importlib.import_module("finrl.meta.env_stock_trading.env_stocktrading_stoploss")
+            cls = mod.StockTradingEnvStopLoss
+            ekw.update(stoploss_penalty=kw.get("stoploss_penalty", 0.9),
+                       profit_loss_ratio=kw.get("profit_loss_ratio", 2))
+        with contextlib.redirect_stdout(printed):
+            env = cls(df=df, **ekw)
+            # first information column of every asset
+            model = hl.ScriptedModel(base, 1 + N + len(cols) * np.arange(N))
+            try:
+                acct, acts = hl.drl_prediction(model, env)
+                raised = ""
+            except IndexError as ex:      # episode cut short by a cash shortage: the reference's
+                acct = acts = pd.DataFrame()    # loop then indexes an empty list (models.py:129)
+                raised = f"IndexError: {ex}"
+        out["raised"] = np.array(raised)
+        out["model_steps"] = np.array(model.step, np.int64)
+        info = np.stack([data[c] for c in cols], axis=2)
+        out.update(close=close, info=info, turb=turb, cols=np.asarray(cols),
+                   cfg_int=np.array([T, N, len(cols), int(ekw["discrete_actions"]),
+                                     ekw["shares_increment"],
+                                     int(ekw["turbulence_threshold"] is not None),
+                                     int(ekw["patient"]), ekw["print_verbosity"]], np.int64),
+                   cfg_float=np.array([ekw["hmax"], 3e-3, 3e-3, ekw["initial_amount"], 0.1,
+                                       ekw["turbulence_threshold"] or 0.0,
+                                       ekw.get("stoploss_penalty", 0.0),
+                                       ekw.get("profit_loss_ratio", 0.0)]))
+        for k, v in _df_columns(acct).items():
+            out[f"account_{k}"] = v
+        for k, v in _df_columns(acts).items():
+            out[f"action_{k}"] = v
+    elif kind == "stock_f64actions":
+        # non-SB3 callers hand float64 arrays / Python lists: the reference scales them in the
+        # CALLER's dtype (env_stocktrading.py:304-305), which truncates differently from float32
+        mod = rh.stable_argsort_patch(rh.load_stocktrading())
+        close, tech, risk = synth_panel(seed, T, N, K)
+        names = [f"ind{k}" for k in range(K)]
+        df = rh.make_stock_frame(close, tech, risk, names, risk_col="turbulence")
+        act64 = np.round(rng.uniform(-1, 1, (T - 1, N)), 2)         # 0.29 * 100 -> 28.999999...
+        with contextlib.redirect_stdout(printed):
+            env = mod.StockTradingEnv(df=df, stock_dim=N, hmax=100, initial_amount=200_000,
+                                      num_stock_shares=[0] * N, buy_cost_pct=1e-3,
+                                      sell_cost_pct=1e-3, reward_scaling=1e-4,
+                                      state_space=1 + 2 * N + K * N, action_space=N,
+                                      tech_indicator_list=names, print_verbosity=10 ** 9)
+            env.reset()
+            rec = dict(reward=[], cash=[], shares=[], realised=[])
+            for s_ in range(T - 1):
+                a_in = act64[s_].copy() if s_ % 2 == 0 else act64[s_].tolist()   # array / list
+                if isinstance(a_in, list):
+                    a_in = np.array(a_in)      # (a list * int would repeat it: callers pass arrays)
+                obs, rew, done, _ = env.step(a_in)
+                rec["reward"].append(float(rew))
+                rec["cash"].append(float(env.state[0]))
+                rec["shares"].append(np.asarray(env.state[1 + N:1 + 2 * N], np.int64))
+                rec["realised"].append(np.asarray(env.actions_memory[-1], np.int64))
+        n_diff = int(((act64 * 100).astype(int) !=
+                      (act64.astype(np.float32) * np.float32(100)).astype(int)).sum())
+        assert n_diff > 0, "scenario must contain actions that truncate differently in float32"
+        out.update(close=close, tech=tech, risk=risk, actions64=act64,
+                   cfg_int=np.array([T, N, K, n_diff], np.int64),
+                   reward=np.asarray(rec["reward"]), cash=np.asarray(rec["cash"]),
+                   shares=np.stack(rec["shares"]), realised=np.stack(rec["realised"]))
+    elif kind == "erl_stocknp":
+        mod = rh.load_stocktrading_np()
+        price = 100 * np.exp(np.cumsum(rng.normal(0, 0.01, (T, N)), axis=0))
+        tech = rng.normal(0, 50, (T, N * K))
+        turb = np.abs(rng.normal(0, 60, T))
+        env = mod.StockTradingEnv({"price_array": price, "tech_array": tech,
+                                   "turbulence_array": turb, "if_train": False})
+        # the scaled price columns of the state (env_stocktrading_np.py:149-162)
+        act = hl.scripted_act(base, 3 + np.arange(N))
+        with contextlib.redirect_stdout(printed):
+            assets, returns = hl.elegantrl_prediction(act, env)
+        out.update(price_array=price, tech_array=tech, turbulence_array=turb,
+                   cfg_int=np.array([T, N, K], np.int64),
+                   episode_total_assets=np.asarray(assets, np.float64),
+                   episode_returns=np.asarray(returns, np.float64))
+    else:
+        raise ValueError(kind)
+    out["printed"] = np.array(printed.getvalue())
+    path = os.path.join(HERE, f"harness_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB)  kind={kind} "
+          f"printed_lines={printed.getvalue().count(chr(10))}")
+    return out
+
+
+HARNESS_SCENARIOS = {
+    "sb3_stock": dict(kind="sb3_stock", seed=81, T=26, N=30, K=8, initial_amount=150_000),
+    "sb3_stock_turb": dict(kind="sb3_stock", seed=82, T=20, N=7, K=3, turbulence_threshold=35.0,
+                           flag_frac=0.05, initial_amount=40_000),
+    "sb3_cashpenalty": dict(kind="sb3_cashpenalty", seed=83, T=24, N=30, hmax=20_000,
+                            turbulence_threshold=55.0),
+    "sb3_cashpenalty_patient": dict(kind="sb3_cashpenalty", seed=84, T=20, N=5, hmax=400_000,
+                                    patient=True, cols=("close", "volume")),
+    "sb3_cashpenalty_shortage": dict(kind="sb3_cashpenalty", seed=85, T=20, N=5, hmax=600_000),
+    "sb3_stoploss": dict(kind="sb3_stoploss", seed=86, T=30, N=8, hmax=60_000, sigma=0.05,
+                         turbulence_threshold=70.0),
+    "sb3_stoploss_patient": dict(kind="sb3_stoploss", seed=87, T=24, N=5, hmax=300_000,
+                                 sigma=0.05, patient=True),
+    "erl_stocknp": dict(kind="erl_stocknp", seed=88, T=40, N=30, K=8),
+    "stock_f64actions": dict(kind="stock_f64actions", seed=89, T=16, N=30, K=2),
+}
+
+
+
 def main(argv):
     names = argv or (list(STOCK_SCENARIOS) + ["portfolio:" + k for k in PORTFOLIO_SCENARIOS]
                      + ["crypto:" + k for k in CRYPTO_SCENARIOS]
                      + ["stocknp:" + k for k in STOCKNP_SCENARIOS]
                      + ["cashpenalty:" + k for k in CASHPENALTY_SCENARIOS]
                      + ["stoploss:" + k for k in STOPLOSS_SCENARIOS]
-                     + ["riskpre:" + k for k in RISKPRE_SCENARIOS])
+                     + ["riskpre:" + k for k in RISKPRE_SCENARIOS]
+                     + ["harness:" + k for k in HARNESS_SCENARIOS])
     for n in names:
         if n in STOCK_SCENARIOS:
             run_stock(n, **STOCK_SCENARIOS[n])
@@ -725,6 +916,8 @@ def main(argv):
             run_cashpenalty(n[12:], **CASHPENALTY_SCENARIOS[n[12:]])
         elif n.startswith("stoploss:") and n[9:] in STOPLOSS_SCENARIOS:
             run_stoploss(n[9:], **STOPLOSS_SCENARIOS[n[9:]])
+        elif n.startswith("harness:") and n[8:] in HARNESS_SCENARIOS:
+            run_harness(n[8:], **HARNESS_SCENARIOS[n[8:]])
         elif n.startswith("riskpre:") and n[8:] in RISKPRE_SCENARIOS:
             run_riskpre(n[8:], **RISKPRE_SCENARIOS[n[8:]])
         elif n.startswith("stocknp:") and n[8:] in STOCKNP_SCENARIOS:

@@ -124,7 +124,7 @@ def test_dollar_env_facades_replay_reference_episode(kind):
         state, rew, done, info = env.step(z["actions"][s])
         assert done == bool(z["done"][s]) and env.date_index == z["date_index"][s]
         np.testing.assert_allclose(state, z["obs"][s], rtol=1e-12, atol=1e-12)
-        assert rew == pytest.approx(z["reward"][s], rel=1e-6, abs=1e-12)
+        assert rew == pytest.approx(z["reward"][s], rel=1e-12, abs=1e-15)   # f64 (audit row)
         assert env.cash_on_hand == pytest.approx(z["coh"][s], rel=1e-12)
         np.testing.assert_allclose(env.holdings, z["holdings"][s], rtol=1e-12, atol=1e-12)
         if kind == "stoploss":

@@ -20,7 +20,7 @@ def test_documented_ctypes_stub_runs_and_matches():
     from finrl_amd.vec_env import VecStockTradingEnv
 
     L = C.CDLL(os.path.join(ROOT, "finrl_amd", "lib", "libfinenv.so"))
-    assert L.finenv_abi_version() == 2
+    assert L.finenv_abi_version() == 3
 
     class Cfg(C.Structure):                      # finenv_stock_config
         _fields_ = [(n, C.c_int32) for n in ("n_envs", "n_tickers", "n_tech", "n_days", "hmax",

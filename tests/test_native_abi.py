@@ -28,7 +28,7 @@ def test_exports_every_declared_symbol(L):
 
 def test_struct_layouts_match(L):
     from finrl_amd import _native as nat
-    assert L.finenv_abi_version() == 2
+    assert L.finenv_abi_version() == nat.ABI_VERSION == 3
     assert L.finenv_struct_size(0) == C.sizeof(nat.StockConfig)
     assert L.finenv_struct_size(1) == C.sizeof(nat.StockPanelPtrs)
     assert L.finenv_struct_size(2) == C.sizeof(nat.StockStatePtrs)
