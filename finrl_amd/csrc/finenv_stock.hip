@@ -21,106 +21,9 @@
 //     cash/holdings from LDS.
 // HBM-bound by design (no MFMA: there is no contraction here).
 
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-
-#include <new>
-#include <type_traits>
-
-#include "finenv.h"
-#include "finenv_dev.h"
-#include "finenv_host.h"
+#include "finenv_stock_common.h"
 
 namespace {
-
-constexpr int kWave = 64;
-constexpr int kStepThreads = 2 * kWave;
-#ifndef FINENV_TRADE_UNROLL
-#define FINENV_TRADE_UNROLL 2     // unroll factor of the rolled sell / buy loops (tuning switch)
-#endif
-
-struct Params {
-    finenv_stock_config cfg;
-    finenv_stock_panel panel;
-    finenv_stock_state st;
-    const float *actions;
-    float *obs;
-    float *reward;
-    uint8_t *done;
-    float *term_obs;
-    int32_t *realised;
-    const uint8_t *mask;
-    double *stats_out;
-    int32_t auto_reset;
-    int32_t D;
-    int32_t day0;
-    uint32_t magicN;      // ceil(2^32 / N) for N >= 2 (exact f / N for f < 2^16)
-    int32_t diag;         // FINENV_DIAG builds only: phase-skip bitmask (timing experiments)
-    unsigned long long *dbg;   // FINENV_DIAG builds only: [block][role][16] s_memrealtime stamps
-};
-
-#ifdef FINENV_DIAG
-#define DIAG(bit) (p.diag & (bit))
-// phase stamps (100 MHz wall clock) for tools/phase_times.py; diagnostic build only
-#define STAMP(k)                                                                          \
-    do {                                                                                  \
-        if (p.dbg != nullptr && lane == 0) {                                              \
-            __builtin_amdgcn_sched_barrier(0);                                            \
-            p.dbg[((size_t)blockIdx.x * 2 + role) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
-            __builtin_amdgcn_sched_barrier(0);                                            \
-        }                                                                                 \
-    } while (0)
-#else
-#define DIAG(bit) 0
-#define STAMP(k) do { } while (0)
-#endif
-
-// per-env state fields: [field][env] blocks (include/finenv.h)
-#define SF(fld) (*at(p.st.f64, (unsigned)(fld) * (unsigned)E + (unsigned)e))
-#define SI(fld) (*at(p.st.i32, (unsigned)(fld) * (unsigned)E + (unsigned)e))
-#define HOLD(i) SI(FINENV_STOCK_I32_FIELDS + (i))
-#define SH0(i) SI(FINENV_STOCK_I32_FIELDS + N + (i))
-
-__device__ __forceinline__ void ce(int &a, int &b)
-{
-    const int lo = min(a, b);
-    const int hi = max(a, b);
-    a = lo;
-    b = hi;
-}
-
-namespace np32 {
-#define FINENV_NP 32
-#define FINENV_LOG2NP 5
-#define FINENV_SORTNET "sortnet32.inc"
-#include "finenv_stock_kernels.inc"
-#undef FINENV_NP
-#undef FINENV_LOG2NP
-#undef FINENV_SORTNET
-}  // namespace np32
-
-namespace np64 {
-#define FINENV_NP 64
-#define FINENV_LOG2NP 6
-#define FINENV_SORTNET "sortnet64.inc"
-#include "finenv_stock_kernels.inc"
-#undef FINENV_NP
-#undef FINENV_LOG2NP
-#undef FINENV_SORTNET
-}  // namespace np64
-
-namespace np128 {
-#define FINENV_NP 128
-#define FINENV_LOG2NP 7
-#define FINENV_SORTNET "sortnet128.inc"
-#include "finenv_stock_kernels.inc"
-#undef FINENV_NP
-#undef FINENV_LOG2NP
-#undef FINENV_SORTNET
-}  // namespace np128
 
 // Terminal summary :226-264 from current state: one lane per env.
 __global__ void stock_stats_kernel(const Params p)
@@ -196,57 +99,21 @@ Params make_params(const finenv_stock *h)
     return p;
 }
 
-// aux kernel (init / reset / observe): kAuxWaves waves per block
-template <int AUXW>
-dim3 aux_grid(int E)
-{
-    const int waves = (E + kWave - 1) / kWave;
-    return dim3((unsigned)((waves + AUXW - 1) / AUXW));
-}
-
 int launch_aux(finenv_stock *h, const Params &p, int mode, hipStream_t stream)
 {
-    if (h->cfg.n_tickers <= 32)
-        hipLaunchKernelGGL(np32::stock_aux_kernel, aux_grid<np32::kAuxWaves>(h->cfg.n_envs),
-                           dim3(kWave * np32::kAuxWaves), 0, stream, p, mode);
-    else if (h->cfg.n_tickers <= 64)
-        hipLaunchKernelGGL(np64::stock_aux_kernel, aux_grid<np64::kAuxWaves>(h->cfg.n_envs),
-                           dim3(kWave * np64::kAuxWaves), 0, stream, p, mode);
-    else
-        hipLaunchKernelGGL(np128::stock_aux_kernel, aux_grid<np128::kAuxWaves>(h->cfg.n_envs),
-                           dim3(kWave * np128::kAuxWaves), 0, stream, p, mode);
+    if (h->cfg.n_tickers <= 32) finenv_stock_impl::launch_aux_np32(p, mode, stream);
+    else if (h->cfg.n_tickers <= 64) finenv_stock_impl::launch_aux_np64(p, mode, stream);
+    else finenv_stock_impl::launch_aux_np128(p, mode, stream);
     return 0;
 }
 
-// step kernel: one 128-thread block per 64 envs, dynamic LDS = R1 + R2 + R3
-template <bool TURB, bool STATS>
-int launch_step(finenv_stock *h, const Params &p, hipStream_t stream)
+// step kernel: one 128-thread block per 64 envs; 33..64 tickers use the 128-wide code paths at
+// half the padding (34 KB of LDS, four blocks per CU instead of two)
+int launch_step(finenv_stock *h, const Params &p, bool turb, bool stats, hipStream_t stream)
 {
-    const dim3 grid((unsigned)((h->cfg.n_envs + kWave - 1) / kWave)), block(kStepThreads);
-    if (h->cfg.n_tickers <= 32) {
-        constexpr size_t lds = sizeof(float) * (np32::kR1 + np32::kR2 + np32::kR3);
-        hipLaunchKernelGGL((np32::stock_step_kernel<TURB, STATS>), grid, block, lds, stream, p);
-    } else if (h->cfg.n_tickers <= 64) {
-        // 33..64 tickers: the 128-wide code paths at half the padding -- 34 KB of LDS, four
-        // blocks per CU (all 1024 resident at 65,536 envs) instead of two
-        constexpr size_t lds = sizeof(float) * (np64::kR1 + np64::kR2 + np64::kR3);
-        hipLaunchKernelGGL((np64::stock_step_kernel<TURB, STATS>), grid, block, lds, stream, p);
-    } else {
-        constexpr size_t lds = sizeof(float) * (np128::kR1 + np128::kR2 + np128::kR3);
-        // > 64 KiB of dynamic LDS needs an explicit opt-in, once per device (a process may
-        // hold handles on several GPUs)
-        static unsigned long long attr_set_mask = 0ull;
-        const int dev = h->device >= 0 && h->device < 64 ? h->device : 0;
-        if (!((attr_set_mask >> dev) & 1ull)) {
-            if (hipFuncSetAttribute(
-                    reinterpret_cast<const void *>(&np128::stock_step_kernel<TURB, STATS>),
-                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return -1;
-            attr_set_mask |= 1ull << dev;
-        }
-        hipLaunchKernelGGL((np128::stock_step_kernel<TURB, STATS>), grid, block, lds, stream, p);
-    }
-    return 0;
+    if (h->cfg.n_tickers <= 32) return finenv_stock_impl::launch_step_np32(p, turb, stats, h->device, stream);
+    if (h->cfg.n_tickers <= 64) return finenv_stock_impl::launch_step_np64(p, turb, stats, h->device, stream);
+    return finenv_stock_impl::launch_step_np128(p, turb, stats, h->device, stream);
 }
 
 }  // namespace
@@ -422,11 +289,7 @@ int finenv_stock_step(finenv_stock *h, const float *actions, float *obs, float *
 #endif
     const hipStream_t s = (hipStream_t)stream;
     const bool turb = h->cfg.use_turbulence != 0, stats = h->cfg.track_stats != 0;
-    int rc;
-    if (turb && stats) rc = launch_step<true, true>(h, p, s);
-    else if (turb) rc = launch_step<true, false>(h, p, s);
-    else if (stats) rc = launch_step<false, true>(h, p, s);
-    else rc = launch_step<false, false>(h, p, s);
+    const int rc = launch_step(h, p, turb, stats, s);
     if (rc) return fail(h, FINENV_ERR_HIP, "step: cannot raise the dynamic LDS limit%s");
     return check_launch(h, "stock_step");
 }

@@ -1,0 +1,57 @@
+// finenv_stock_np128.hip -- step / aux kernels of the batched StockTradingEnv for N <= 128 tickers
+// (finenv_stock_kernels.inc compiled with FINENV_NP = 128); design notes: finenv_stock.hip.
+#include "finenv_stock_common.h"
+
+namespace {
+namespace np128 {
+#define FINENV_NP 128
+#define FINENV_LOG2NP 7
+#define FINENV_SORTNET "sortnet128.inc"
+#include "finenv_stock_kernels.inc"
+#undef FINENV_NP
+#undef FINENV_LOG2NP
+#undef FINENV_SORTNET
+}  // namespace np128
+
+template <bool TURB, bool STATS>
+int launch_step(const Params &p, int device, hipStream_t stream)
+{
+    // one 128-thread block per 64 envs, dynamic LDS = R1 + R2 + R3
+    const dim3 grid((unsigned)((p.cfg.n_envs + kWave - 1) / kWave)), block(kStepThreads);
+    constexpr size_t lds = sizeof(float) * (np128::kR1 + np128::kR2 + np128::kR3);
+    // > 64 KiB of dynamic LDS needs an explicit opt-in, once per device (a process may hold
+    // handles on several GPUs)
+    if (lds > 64 * 1024) {
+        static unsigned long long attr_set_mask = 0ull;
+        const int dev = device >= 0 && device < 64 ? device : 0;
+        if (!((attr_set_mask >> dev) & 1ull)) {
+            if (hipFuncSetAttribute(
+                    reinterpret_cast<const void *>(&np128::stock_step_kernel<TURB, STATS>),
+                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return -1;
+            attr_set_mask |= 1ull << dev;
+        }
+    }
+    hipLaunchKernelGGL((np128::stock_step_kernel<TURB, STATS>), grid, block, lds, stream, p);
+    return 0;
+}
+}  // namespace
+
+namespace finenv_stock_impl {
+
+int launch_step_np128(const Params &p, bool turb, bool stats, int device, hipStream_t stream)
+{
+    if (turb && stats) return launch_step<true, true>(p, device, stream);
+    if (turb) return launch_step<true, false>(p, device, stream);
+    if (stats) return launch_step<false, true>(p, device, stream);
+    return launch_step<false, false>(p, device, stream);
+}
+
+void launch_aux_np128(const Params &p, int mode, hipStream_t stream)
+{
+    const int waves = (p.cfg.n_envs + kWave - 1) / kWave;
+    const dim3 grid((unsigned)((waves + np128::kAuxWaves - 1) / np128::kAuxWaves));
+    hipLaunchKernelGGL(np128::stock_aux_kernel, grid, dim3(kWave * np128::kAuxWaves), 0, stream, p, mode);
+}
+
+}  // namespace finenv_stock_impl
