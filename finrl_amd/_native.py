@@ -44,14 +44,13 @@ class StockConfig(C.Structure):
 
 
 class StockPanelPtrs(C.Structure):
-    _fields_ = [("close", C.c_void_p), ("obs_tmpl", C.c_void_p), ("untradable", C.c_void_p),
-                ("risk", C.c_void_p)]
+    _fields_ = [("close", C.c_void_p), ("obs_tmpl", C.c_void_p), ("risk", C.c_void_p)]
 
 
 # Field order of the two [field][E] state blocks (include/finenv.h enums)
-STOCK_F64_FIELDS = ("cash", "cost", "last_reward", "turbulence", "asset0", "prev_asset",
-                    "ret_sum", "ret_sumsq", "cash0")
-STOCK_I32_FIELDS = ("day", "price_day", "trades", "episode", "n_ret")
+STOCK_F64_FIELDS = ("cash", "cost", "last_reward", "turbulence", "asset0", "ret_sum", "ret_sumsq",
+                    "cash0")
+STOCK_I32_FIELDS = ("day", "price_day", "trades", "episode", "start_day")
 
 
 class StockStatePtrs(C.Structure):

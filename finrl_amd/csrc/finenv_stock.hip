@@ -33,7 +33,7 @@ __global__ void stock_stats_kernel(const Params p)
     if (e >= E) return;
     const double *prow = p.panel.close + (size_t)SI(FINENV_SI_PRICE_DAY) * N;
     double s = 0.0;
-    for (int i = 0; i < N; ++i) s = s + prow[i] * (double)HOLD(i);
+    for (int i = 0; i < N; ++i) s = s + fabs(prow[i]) * (double)HOLD(i);   // sign bit = flag
     const double end = SF(FINENV_SF_CASH) + s;
     const double a0 = SF(FINENV_SF_ASSET0);
     double *out = p.stats_out + (size_t)e * 6;
@@ -43,7 +43,7 @@ __global__ void stock_stats_kernel(const Params p)
     out[3] = SF(FINENV_SF_COST);
     out[4] = (double)SI(FINENV_SI_TRADES);
     double sharpe = __builtin_nan("");
-    const int n = SI(FINENV_SI_N_RET);
+    const int n = SI(FINENV_SI_DAY) - SI(FINENV_SI_START_DAY);   // daily returns accumulated
     if (n >= 2) {        // sqrt(252) * mean / std(ddof=1) from the running sums
         const double s1 = SF(FINENV_SF_RET_SUM), s2 = SF(FINENV_SF_RET_SUMSQ);
         const double mean = s1 / (double)n;
@@ -216,7 +216,7 @@ int finenv_stock_bind(finenv_stock *h, const finenv_stock_panel *panel,
                       const finenv_stock_state *st)
 {
     if (!h || !panel || !st) return FINENV_ERR_INVALID;
-    if (!panel->close || !panel->obs_tmpl || !panel->untradable ||
+    if (!panel->close || !panel->obs_tmpl ||
         (h->cfg.use_turbulence && !panel->risk))
         return fail(h, FINENV_ERR_INVALID, "bind: null panel pointer%s");
     if (!st->f64 || !st->i32)

@@ -8,14 +8,27 @@ namespace np128 {
 #define FINENV_LOG2NP 7
 #define FINENV_SORTNET "sortnet128.inc"
 #include "finenv_stock_kernels.inc"
+#include "finenv_stock_wide.inc"
 #undef FINENV_NP
 #undef FINENV_LOG2NP
 #undef FINENV_SORTNET
 }  // namespace np128
 
+// NASDAQ-100 shape (BASELINE configs[3]): compile-time ticker count, 40.7 KB of LDS, 4 blocks per CU
+template <bool TURB, bool STATS, int NT>
+int launch_step_wide(const Params &p, hipStream_t stream)
+{
+    const dim3 grid((unsigned)((p.cfg.n_envs + kWave - 1) / kWave)), block(kStepThreads);
+    hipLaunchKernelGGL((np128::stock_step_wide_kernel<TURB, STATS, NT>), grid, block,
+                       np128::WideGeom<NT>::kBytes, stream, p);
+    return 0;
+}
+
 template <bool TURB, bool STATS>
 int launch_step(const Params &p, int device, hipStream_t stream)
 {
+    if (p.cfg.n_tickers == 100 && p.cfg.hmax <= np128::WideGeom<100>::kMaxHmax)
+        return launch_step_wide<TURB, STATS, 100>(p, stream);
     // one 128-thread block per 64 envs, dynamic LDS = R1 + R2 + R3
     const dim3 grid((unsigned)((p.cfg.n_envs + kWave - 1) / kWave)), block(kStepThreads);
     constexpr size_t lds = sizeof(float) * (np128::kR1 + np128::kR2 + np128::kR3);

@@ -9,9 +9,10 @@ Reference contracts followed:
     tech_0[N] | ... | tech_{K-1}[N]]  (indicator-major).
 
 Device layout (see include/finenv.h `finenv_stock_panel`):
-  close      f64 [T][N]   money arithmetic runs on the reference's own doubles
+  close      f64 [T][N]   money arithmetic runs on the reference's own doubles; the SIGN BIT carries
+                          the day's "untradable" flag: set <=> tech_0[t][i] == 1.0 evaluated in
+                          fp64 (:105, :174)
   obs_tmpl   f32 [T][D]   ready-made observation rows (cash / holdings slots zero)
-  untradable u32 [T][W]   bit i <=> tech_0[t][i] == 1.0 evaluated in fp64 (:105, :174)
   risk       f64 [T]
 The whole DOW30 x 8 x 2893-day panel is 4.2 MB: it stays resident in L2 / Infinity Cache,
 so per-step HBM traffic is the per-env state, actions and observations only.
@@ -85,18 +86,19 @@ class StockPanel:
         out[:, 1 + 2 * N:] = self.tech.reshape(T, K * N).astype(np.float32)
         return out
 
-    def untradable_bits(self) -> np.ndarray:
-        """u32 [T, W]: bit i (word i // 32) set iff the first indicator of ticker i equals 1.0
-        (fp64 compare).  W = 1 for N <= 32, 4 for N <= 128 (the two kernel variants)."""
+    def signed_close(self) -> np.ndarray:
+        """f64 [T, N]: the closes with the fork's "untradable" flag in the sign bit -- set iff the
+        first indicator of that ticker equals 1.0 on that day (fp64 compare; :105, :174).  The
+        kernels use |close| for every valuation and the sign only in the trade rules."""
         if self.N > 128:
             raise ValueError("the stock kernels support N <= 128 tickers")
-        W = 1 if self.N <= 32 else 4
-        bits = np.zeros((self.T, W), dtype=np.uint32)
+        if (self.close < 0).any():
+            raise ValueError("closes must be >= 0 (the sign bit is the untradable flag)")
+        out = np.abs(self.close)              # also turns any -0.0 into +0.0
         if self.K:
             flag = self.tech[:, 0, :] == 1.0
-            for i in range(self.N):
-                bits[:, i // 32] |= (flag[:, i].astype(np.uint32) << np.uint32(i % 32))
-        return bits
+            out = np.where(flag, np.copysign(out, -1.0), out)
+        return np.ascontiguousarray(out)
 
     def to_device(self, device):
         """-> dict of torch tensors on `device` (cached per device)."""
@@ -104,15 +106,14 @@ class StockPanel:
         key = str(device)
         if key not in self._device_cache:
             self._device_cache[key] = dict(
-                close=torch.from_numpy(self.close).to(device),
+                close=torch.from_numpy(self.signed_close()).to(device),
                 obs_tmpl=torch.from_numpy(self.obs_template()).to(device),
-                untradable=torch.from_numpy(self.untradable_bits().view(np.int32)).to(device),
                 risk=torch.from_numpy(self.risk).to(device),
             )
         return self._device_cache[key]
 
     def nbytes_device(self):
-        return self.T * (8 * self.N + 4 * self.D + 4 + 8)
+        return self.T * (8 * self.N + 4 * self.D + 8)
 
 
 class PortfolioPanel:

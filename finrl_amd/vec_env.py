@@ -93,7 +93,7 @@ class VecStockTradingEnv:
         self.state["shares0"].copy_(torch.from_numpy(np.ascontiguousarray(sh0.T).astype(np.int32)))
         self._panel_t = panel.to_device(dev)
         pp = nat.StockPanelPtrs(*(self._panel_t[k].data_ptr()
-                                  for k in ("close", "obs_tmpl", "untradable", "risk")))
+                                  for k in ("close", "obs_tmpl", "risk")))
         sp = nat.StockStatePtrs(self._state_f64.data_ptr(), self._state_i32.data_ptr())
         nat.check(L.finenv_stock_bind(self._h, C.byref(pp), C.byref(sp)), self._h, "bind")
 

@@ -77,14 +77,15 @@ typedef struct finenv_stock_config {
  * (date, tic): preprocessors.py:24-33). */
 typedef struct finenv_stock_panel {
     const double   *close;        /* [T][N]  fp64 closes: the money arithmetic runs on
-                                     the same doubles the reference holds in state[1..N] */
+                                     the same doubles the reference holds in state[1..N].
+                                     The SIGN BIT of close[t][i] carries the day's
+                                     "untradable" flag of ticker i: set <=> its first
+                                     indicator == 1.0 on day t (the fork's `!= True` test,
+                                     :105, :174, evaluated on the fp64 values); prices
+                                     themselves are >= 0 by contract                     */
     const float    *obs_tmpl;     /* [T][D]  f32 observation rows with the cash and
                                      holdings slots zero: f32(close) and f32(tech) in obs
                                      order (what DummyVecEnv's float32 buffer would hold) */
-    const uint32_t *untradable;   /* [T][W]  W = 1 (N <= 32) or 4 (33 <= N <= 128) words per day;
-                                     bit i set <=> first indicator of ticker i
-                                     == 1.0 on that day (the fork's `!= True` test,
-                                     :105, :174), evaluated on the fp64 values           */
     const double   *risk;         /* [T]     df[risk_indicator_col], :337-341 (may be
                                      NULL when use_turbulence == 0)                      */
 } finenv_stock_panel;
@@ -98,8 +99,9 @@ enum {                            /* f64 block: double f64[FINENV_STOCK_F64_FIEL
     FINENV_SF_COST,               /* self.cost                                           */
     FINENV_SF_LAST_REWARD,        /* self.reward (scaled; survives reset)                */
     FINENV_SF_TURBULENCE,         /* self.turbulence                                     */
-    FINENV_SF_ASSET0,             /* asset_memory[0]                                     */
-    FINENV_SF_PREV_ASSET,         /* asset_memory[-1]                                    */
+    FINENV_SF_ASSET0,             /* asset_memory[0] (written by init / reset only; the
+                                     running asset_memory[-1] is never stored: it equals
+                                     the next step's begin asset bit for bit)            */
     FINENV_SF_RET_SUM,            /* sum of pct_change(asset_memory) this episode        */
     FINENV_SF_RET_SUMSQ,          /* sum of its squares (Sharpe at the terminal step)    */
     FINENV_SF_CASH0,              /* initial_amount / previous_state[0] (read-only)      */
@@ -112,7 +114,8 @@ enum {                            /* i32 block: int32 i32[FINENV_STOCK_I32_FIELD
                                      reset)                                              */
     FINENV_SI_TRADES,             /* self.trades                                         */
     FINENV_SI_EPISODE,            /* self.episode                                        */
-    FINENV_SI_N_RET,              /* number of daily returns accumulated                 */
+    FINENV_SI_START_DAY,          /* day the episode started on (init: day0, reset: 0);
+                                     daily returns accumulated so far = day - start_day  */
     FINENV_STOCK_I32_FIELDS       /* followed by holdings[N][E] = state[1+N .. 1+2N) and
                                      shares0[N][E] = num_stock_shares / previous_state
                                      shares (read-only)                                  */

@@ -29,7 +29,7 @@ def test_documented_ctypes_stub_runs_and_matches():
                     "turbulence_threshold")]
 
     class Panel(C.Structure):                    # finenv_stock_panel
-        _fields_ = [(n, C.c_void_p) for n in ("close", "obs_tmpl", "untradable", "risk")]
+        _fields_ = [(n, C.c_void_p) for n in ("close", "obs_tmpl", "risk")]
 
     class State(C.Structure):                    # finenv_stock_state
         _fields_ = [("f64", C.c_void_p), ("i32", C.c_void_p)]
@@ -43,12 +43,11 @@ def test_documented_ctypes_stub_runs_and_matches():
     E, N, K, T = 200, 30, 8, 50
     D = 1 + 2 * N + K * N
     dev = "cuda"
-    f64 = torch.zeros(9, E, dtype=torch.float64, device=dev)          # FINENV_SF_* rows
+    f64 = torch.zeros(8, E, dtype=torch.float64, device=dev)          # FINENV_SF_* rows
     i32 = torch.zeros(5 + 2 * N, E, dtype=torch.int32, device=dev)    # FINENV_SI_* rows, holdings, shares0
-    f64[8] = 1_000_000.0                                              # FINENV_SF_CASH0
-    close_t = torch.from_numpy(panel.close).to(dev)
+    f64[7] = 1_000_000.0                                              # FINENV_SF_CASH0
+    close_t = torch.from_numpy(panel.signed_close()).to(dev)          # sign bit = untradable flag
     tmpl = torch.from_numpy(panel.obs_template()).to(dev)
-    untr = torch.from_numpy(panel.untradable_bits().view(np.int32)).to(dev)
     risk_t = torch.from_numpy(panel.risk).to(dev)
     obs = torch.zeros(E, D, dtype=torch.float32, device=dev)
     reward = torch.zeros(E, dtype=torch.float32, device=dev)
@@ -59,8 +58,7 @@ def test_documented_ctypes_stub_runs_and_matches():
     L.finenv_stock_create.argtypes = [C.POINTER(Cfg), C.POINTER(C.c_void_p)]
     assert L.finenv_stock_create(C.byref(cfg), C.byref(h)) == 0
     L.finenv_stock_bind.argtypes = [C.c_void_p, C.POINTER(Panel), C.POINTER(State)]
-    assert L.finenv_stock_bind(h, C.byref(Panel(close_t.data_ptr(), tmpl.data_ptr(), untr.data_ptr(),
-                                                risk_t.data_ptr())),
+    assert L.finenv_stock_bind(h, C.byref(Panel(close_t.data_ptr(), tmpl.data_ptr(), risk_t.data_ptr())),
                                C.byref(State(f64.data_ptr(), i32.data_ptr()))) == 0
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     L.finenv_stock_init.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
