@@ -29,9 +29,9 @@ int launch_step(const Params &p, int device, hipStream_t stream)
 {
     if (p.cfg.n_tickers == 100 && p.cfg.hmax <= np128::WideGeom<100>::kMaxHmax)
         return launch_step_wide<TURB, STATS, 100>(p, stream);
-    // one 128-thread block per 64 envs, dynamic LDS = R1 + R2 + R3
+    // one 128-thread block per 64 envs, dynamic LDS = kLdsStep
     const dim3 grid((unsigned)((p.cfg.n_envs + kWave - 1) / kWave)), block(kStepThreads);
-    constexpr size_t lds = sizeof(float) * (np128::kR1 + np128::kR2 + np128::kR3);
+    constexpr size_t lds = sizeof(float) * np128::kLdsStep;
     // > 64 KiB of dynamic LDS needs an explicit opt-in, once per device (a process may hold
     // handles on several GPUs)
     if (lds > 64 * 1024) {

@@ -16,9 +16,9 @@ namespace np64 {
 template <bool TURB, bool STATS>
 int launch_step(const Params &p, int device, hipStream_t stream)
 {
-    // one 128-thread block per 64 envs, dynamic LDS = R1 + R2 + R3
+    // one 128-thread block per 64 envs, dynamic LDS = kLdsStep
     const dim3 grid((unsigned)((p.cfg.n_envs + kWave - 1) / kWave)), block(kStepThreads);
-    constexpr size_t lds = sizeof(float) * (np64::kR1 + np64::kR2 + np64::kR3);
+    constexpr size_t lds = sizeof(float) * np64::kLdsStep;
     (void)device;
     hipLaunchKernelGGL((np64::stock_step_kernel<TURB, STATS>), grid, block, lds, stream, p);
     return 0;

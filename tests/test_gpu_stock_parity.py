@@ -113,6 +113,10 @@ def _random_panel(seed, T, N, K, flag_frac=0.03):
     dict(E=200, T=14, N=100, K=8, steps=32, thr=40.0, cash=400_000, hmax=100),
     dict(E=70, T=10, N=33, K=1, steps=24, thr=None, cash=50_000, hmax=50),
     dict(E=64, T=9, N=128, K=1, steps=20, thr=None, cash=900_000, hmax=200),
+    # N = 100 compile-time variant: int16 key limit (hmax <= 255), a 1-lane tail block, and the
+    # generic 128-wide kernel it falls back to above that limit
+    dict(E=65, T=9, N=100, K=2, steps=20, thr=None, cash=2_000_000, hmax=255),
+    dict(E=130, T=9, N=100, K=1, steps=20, thr=60.0, cash=3_000_000, hmax=1000),
     # 64-wide variant (33..64 tickers)
     dict(E=300, T=16, N=50, K=4, steps=36, thr=35.0, cash=200_000, hmax=100),
     dict(E=129, T=11, N=64, K=2, steps=26, thr=None, cash=80_000, hmax=300),
@@ -165,13 +169,15 @@ def test_hip_matches_oracle_random_batch(cfg):
     assert n_done >= 2
 
 
-def test_hip_desynchronised_envs():
+@pytest.mark.parametrize("N,K", [(30, 8), (100, 3), (50, 2)])
+def test_hip_desynchronised_envs(N, K):
     """Envs that are NOT in lock-step (different days inside one wave, via masked resets):
-    exercises the per-row reload path of the observation writer and per-lane price gathers."""
+    exercises the per-row reload path of the observation writer and per-lane price gathers, in
+    every kernel variant (32-wide, the N = 100 one, 64-wide)."""
     _need_gpu()
     from finrl_amd import StockPanel
     from oracle.stock import StockOracle, lib, _p
-    E, T, N, K = 200, 30, 30, 8
+    E, T = 200, 30
     close, tech, risk = _random_panel(5, T, N, K)
     rng = np.random.default_rng(9)
     kw = dict(hmax=100, initial_amount=300_000, turbulence_threshold=50.0)

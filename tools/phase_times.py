@@ -43,7 +43,8 @@ def main():
     names_t = ["start", "day/pd loaded", "pre-barrier work done", "barrier passed",
                "begin asset", "sorted", "sells done", "buys done", "end asset", "reward/stats",
                "obs chunk0 written", "state written"]
-    names_s = ["start", "day/pd loaded", "tile+prices staged", "barrier passed", "streamed"]
+    names_s = ["start", "day/pd loaded", "tile+prices staged", "barrier passed", "streamed",
+               "hand-off chunk written"]
     print(f"E={E} blocks={nb}; times in us since the first wave of the launch started "
           "(median over blocks and 20 launches; p95 in brackets)")
     print("trader wave:")

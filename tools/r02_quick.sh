@@ -20,4 +20,4 @@ for f in sorted(glob.glob(os.path.join(d,t+'_bench*.json'))):
     except Exception as ex:
         print(os.path.basename(f),'ERR',ex)
 PY
-if [ -f finrl_amd/lib/libfinenv_diag.so ]; then python3 tools/phase_times.py 65536 100 > gpurun_out/r02/${TAG}_phase_n100.txt 2>&1; grep -v amdgpu.ids gpurun_out/r02/${TAG}_phase_n100.txt; fi
+if [ -f finrl_amd/lib/libfinenv_diag.so ]; then python3 tools/phase_times.py 65536 100 > gpurun_out/r02/${TAG}_phase_n100.txt 2>&1; grep -v amdgpu.ids gpurun_out/r02/${TAG}_phase_n100.txt; python3 tools/phase_times.py 65536 30 > gpurun_out/r02/${TAG}_phase_n30.txt 2>&1; grep -v amdgpu.ids gpurun_out/r02/${TAG}_phase_n30.txt; fi

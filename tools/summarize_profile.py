@@ -19,7 +19,7 @@ def kernel_stats(d):
     out = {}
     if f:
         for row in csv.DictReader(open(f)):
-            if "stock_step_kernel" in row["Name"]:
+            if "stock_step" in row["Name"]:
                 out = dict(name=row["Name"], calls=int(row["Calls"]),
                            avg_ns=float(row["AverageNs"]), min_ns=float(row["MinNs"]),
                            max_ns=float(row["MaxNs"]), pct=float(row["Percentage"]))
@@ -31,7 +31,7 @@ def pmc(d, counter):
     vals = []
     if f:
         for row in csv.DictReader(open(f)):
-            if "stock_step_kernel" in row.get("Kernel_Name", "") and \
+            if "stock_step" in row.get("Kernel_Name", "") and \
                     row.get("Counter_Name") == counter:
                 vals.append(float(row["Counter_Value"]))
     return vals
