@@ -11,9 +11,22 @@ panel.  A "step" is ONE launch of the step kernel over the who
 (E env-steps), including the terminal/auto-reset step of every episode.  Inputs (panel,
 state, a pool of pre-generated action batches) are resident in HBM before the timed region.
 
+Timing: `--warmup W` untimed steps, then EXACTLY `--steps K` steps between barrier +
+synchronize pairs (HIP events on the launch stream and the host clock; max over ranks).  Before
+the warm-up an untimed, disclosed PREWARM phase (`prewarm_launches` in the JSON; default 2,048
+launches when W < 1,024, then a reset) brings the GPU to its sustained clock: a cold 25-launch run
+measures clock ramp, not the kernel (profiles/r02_short_bench.md: 22.7 us/step cold vs 21.2 after
+the prewarm vs 20.9 in a 8,679-step run).
+
 N > 1: independent env shards per rank (weak scaling), no data-path collective; the only
-collective is the RCCL all_gather of per-env episode returns at each episode end
-(SURVEY.md 8e), inside the timed region.
+collective is the RCCL all_gather of per-env episode returns at each episode end,
+inside the timed region -- and at least once per timed region, so that a short scaling run still
+shows every rank taking part (`rccl` in the JSON).
+
+Other workloads (side metrics and BASELINE configs[2..4]): `--env portfolio|crypto|stocknp|
+cashpenalty|stoploss`, `--tickers 100 --turbulence-pct 90` (configs[3] per-GPU slice),
+`--env crypto --envs-per-gpu 32768 --rollout 16` (configs[4] per-GPU slice: steps write straight
+into [n_steps, E, .] rollout buffers, one GAE scan per segment).
 """
 from __future__ import annotations
 
@@ -31,12 +44,19 @@ sys.path.insert(0, ROOT)
 E_PER_GPU = 65_536
 N_TICKERS, N_TECH, N_DAYS = 30, 8, 2893
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
+PREWARM_DEFAULT = 2048
 
 
 def algorithmic_bytes(N, K):
     """actions 4N + state read (12+4N) + state write (12+4N) + obs write
     4(1+2N+KN) + reward 4 + done 1  ==  4KN + 20N + 33  (1593 B at N=30, K=8)."""
     return 4 * K * N + 20 * N + 33
+
+
+def panel_row_bytes(N, K):
+    """one day's panel row, charged per env-step only in the desynchronised run
+    (per-env rows defeat the broadcast): 4(K+1)N + 4 = 1084 B at N=30, K=8."""
+    return 4 * (K + 1) * N + 4
 
 
 def synth_panel(T=N_DAYS, N=N_TICKERS, K=N_TECH, seed=0):
@@ -54,6 +74,7 @@ ENV_KW = dict(hmax=100, initial_amount=1_000_000, buy_cost_pct=1e-3, sell_cost_p
               reward_scaling=1e-4)      # Stock_NeurIPS2018_SB3.py:251-272 (scalar costs)
 
 
+# ------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(close, tech, risk, budget_s=12.0):
     """Time the oracle (oracle/stock_oracle.c, single thread) on a bounded sample of the same
     workload: the first `Ec` envs of the batch, same panel, same action distribution."""
@@ -149,46 +170,29 @@ def cpu_baseline_threads(close, tech, risk, n_threads, budget_s=6.0):
                        "same workload and oracle as cpu_baseline")
 
 
-def bench_portfolio(args, torch, dev):
-    """BASELINE.json configs[2]: 65,536 vectorised StockPortfolioEnv, DOW30, K=8 (side metric;
-    the driver's default line is the stock env)."""
-    from finrl_amd.panel import PortfolioPanel
-    from finrl_amd.vec_portfolio import VecStockPortfolioEnv
-    E, N, K, T = args.envs_per_gpu, N_TICKERS, N_TECH, N_DAYS
-    close, tech, _ = synth_panel()
-    rets = np.diff(np.log(close), axis=0, prepend=np.log(close[:1]))
-    cov = np.einsum("ti,tj->tij", rets, rets).astype(np.float32).astype(np.float64)
-    env = VecStockPortfolioEnv(PortfolioPanel(close, cov, tech), E, device=dev)
+def cpu_baseline_python(close, tech, risk, budget_s=5.0):
+    """a reference-SHAPED single env of this build's own authorship
+    (oracle/pandas_env.py: DataFrame-backed, Python-list state, pandas `.loc[day]` per step), timed
+    on one host core -- the apples-to-apples interpreter cost beside the C port."""
+    from oracle.pandas_env import PandasStockEnv, make_frame
+    Tb = min(close.shape[0], N_DAYS)
+    env = PandasStockEnv(make_frame(close[:Tb], tech[:Tb], risk[:Tb]), **ENV_KW)
     env.reset()
-    pool = [torch.rand(E, N, device=dev) for _ in range(8)]
-    for i in range(args.warmup):
-        env.step(pool[i & 7])
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    e0.record()
-    for i in range(args.steps):
-        env.step(pool[i & 7])
-    e1.record()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    B = 4 * N + 24 + 4 * N * (N + K) + 5           # SURVEY.md 8(d): 4709 B at N=30, K=8
-    per = e0.elapsed_time(e1) * 1e-3 / args.steps
-    ach = B * E / per / 1e9
-    print(json.dumps({
-        "metric": "env-steps/sec, vectorized StockPortfolioEnv (DOW30, 8 indicators)",
-        "value": E * args.steps / wall, "unit": "env-steps/s", "n_gpus": 1,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-        "data": "synthetic",
-        "config": {"workload": f"{E} vectorized StockPortfolioEnv, DOW30 x 8, T={T}",
-                   "envs_per_gpu": E},
-        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBS, "traffic": side_traffic("portfolio", E),
-                     "kernel": "portfolio_step_kernel", "bytes_per_env_step": B,
-                     "avg_launch_us": per * 1e6}}), flush=True)
+    rng = np.random.default_rng(7)
+    acts = rng.uniform(-1, 1, (64, close.shape[1])).astype(np.float32)
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        _, _, done, _ = env.step(acts[steps & 63])
+        steps += 1
+        if done:
+            env.reset()
+    dt = time.perf_counter() - t0
+    return dict(value=steps / dt, unit="env-steps/s", cores=1, kind="port",
+                sample=f"1 env x {steps} steps ({dt:.1f} s), T={Tb}: pandas/list-state Python env "
+                       "(oracle/pandas_env.py, validated against the reference fixtures)")
 
 
+# ------------------------------------------------------------------------------- workloads
 def side_traffic(kind, E):
     """PMC-measured HBM bytes per launch of a sibling kernel (profiles/side_traffic.json), or None."""
     try:
@@ -200,65 +204,245 @@ def side_traffic(kind, E):
     return None
 
 
-def bench_side(args, torch, dev, kind):
-    """Side metrics: multi-crypto env (BASELINE configs[4] shape: 10 pairs x 4 indicators,
-    1-minute bars) and the array-state (_np) stock env, single GPU."""
-    rng = np.random.default_rng(0)
+def stock_traffic(E, N, thr, desync):
+    """PMC-measured HBM bytes per launch of the stock step kernel (profiles/hbm_traffic.json)."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        for rec in tj.get("records", [tj]):
+            if rec.get("envs_per_gpu") == E and rec.get("tickers") == N and \
+                    bool(rec.get("turbulence")) == (thr is not None) and \
+                    bool(rec.get("desync")) == bool(desync):
+                return rec.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+class Workload:
+    """What the timed loop needs: step(i), episode_return(), and the reporting metadata."""
+    episode_len = None            # steps per episode when every env ends together, else None
+    config_extra = {}
+
+    def step(self, i):
+        self.env.step(self.pool[i % len(self.pool)])
+
+    def reset(self):
+        self.env.reset()
+
+    def episode_return(self):
+        return self.env.episode_return()
+
+
+def build_workload(args, torch, dev, rank):
     E = args.envs_per_gpu
-    if kind == "crypto":
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    rng = np.random.default_rng(0)          # panels are identical on every rank (replicated)
+    w = Workload()
+    w.kind = args.env
+    lo = -1.0
+    if args.env == "stock":
+        from finrl_amd import StockPanel
+        from finrl_amd.vec_env import VecStockTradingEnv
+        N, K, T = args.tickers, N_TECH, N_DAYS
+        close, tech, risk = synth_panel(N=N)
+        thr = None if args.turbulence_pct is None else float(np.percentile(risk, args.turbulence_pct))
+        w.env = VecStockTradingEnv(StockPanel(close, tech, risk), E, device=dev,
+                                   track_stats=not args.no_stats, auto_reset=True,
+                                   turbulence_threshold=thr, **ENV_KW)
+        w.panel_arrays = (close, tech, risk)
+        w.B = algorithmic_bytes(N, K) + (panel_row_bytes(N, K) if args.desync else 0)
+        w.B_note = "4KN + 20N + 33" + (" + per-env panel row 4(K+1)N + 4" if args.desync else "")
+        w.metric = ("env-steps/sec at N parallel envs (DOW30, 8 indicators)" if N == 30 else
+                    f"env-steps/sec at N parallel envs ({N} tickers, 8 indicators)")
+        w.workload = (f"{E} vectorized StockTradingEnv per GPU, " + ("DOW30" if N == 30 else f"{N} tickers")
+                      + f" x 8 indicators, T={T}, random actions"
+                      + (f", turbulence threshold p{args.turbulence_pct:g}" if thr is not None else "")
+                      + (", desynchronised start days" if args.desync else ""))
+        w.kernel = "stock_step_wide_kernel" if (N == 100 and ENV_KW["hmax"] <= 255) else "stock_step_kernel"
+        w.traffic = stock_traffic(E, N, thr, args.desync)
+        w.episode_len = None if args.desync else T
+        w.config_extra = dict(tickers=N, indicators=K, days=T, track_stats=not args.no_stats)
+        w.action_dim = N
+        if args.desync:     # every env on its own day: defeats the panel-row broadcast
+            def _desync():
+                offs = torch.randint(0, T - 1, (E,), generator=gen, device=dev).to(torch.int32)
+                w.env.state["day"].copy_(offs)
+                w.env.state["price_day"].copy_(offs)
+                w.env.state["start_day"].copy_(offs)
+            w.after_reset = _desync
+    elif args.env == "portfolio":
+        from finrl_amd.panel import PortfolioPanel
+        from finrl_amd.riskpre import rolling_covariance
+        from finrl_amd.vec_portfolio import VecStockPortfolioEnv
+        N, K, T = N_TICKERS, N_TECH, N_DAYS
+        # SURVEY.md 8(d) config 3: cov[T, N, N] from a 252-day rolling window of the same kind of
+        # synthetic returns, computed on the device by the risk-precompute kernel
+        # (finenv_riskpre_rolling_cov); the series is generated 252 days longer and the env runs on
+        # the last T days (the tutorial's frame likewise starts at the first full window)
+        close, tech, _ = synth_panel(T=T + 252)
+        cov = rolling_covariance(close, lookback=252, device=dev).cpu().numpy()
+        close, tech = close[252:], tech[252:]
+        cov = cov.astype(np.float32).astype(np.float64)
+        w.env = VecStockPortfolioEnv(PortfolioPanel(close, cov, tech), E, device=dev)
+        w.B = 4 * N + 24 + 4 * N * (N + K) + 5                       # SURVEY.md 8(d): 4709
+        w.B_note = "4N + 24 + 4N(N+K) + 5"
+        w.metric = "env-steps/sec, vectorized StockPortfolioEnv (DOW30, 8 indicators)"
+        w.workload = f"{E} vectorized StockPortfolioEnv per GPU, DOW30 x 8, T={T}, 252-day rolling covariance"
+        w.kernel, w.traffic, w.action_dim, lo = "portfolio_step_kernel", side_traffic("portfolio", E), N, 0.0
+    elif args.env == "crypto":
         from finrl_amd.vec_crypto import VecCryptoEnv
         T, N, W = 43_200, 10, 40
         price = 10.0 ** rng.uniform(0, 4.5, N) * np.exp(
             np.cumsum(rng.normal(0, 0.0005, (T, N)), axis=0))
-        env = VecCryptoEnv({"price_array": price, "tech_array": rng.normal(0, 3000, (T, W))}, E,
-                           device=dev)
-        B = 4 * N + 2 * (28 + 4 * N) + 4 * (1 + N + W) + 5          # SURVEY 8(d): 385
-        name, kern = "vectorized CryptoEnv (10 pairs, 4 indicators/pair)", "crypto_kernel"
-    elif kind in ("cashpenalty", "stoploss"):
+        w.env = VecCryptoEnv({"price_array": price, "tech_array": rng.normal(0, 3000, (T, W))}, E,
+                             device=dev)
+        w.B = 4 * N + 2 * (28 + 4 * N) + 4 * (1 + N + W) + 5          # SURVEY 8(d): 385
+        w.B_note = "4N + 2(28+4N) + 4(1+N+40) + 5"
+        w.metric = "env-steps/sec, vectorized CryptoEnv (10 pairs, 4 indicators/pair)"
+        w.workload = f"{E} vectorized CryptoEnv per GPU, 10 pairs x 4 indicators, 1-minute bars, T={T}"
+        w.kernel, w.traffic, w.action_dim = "crypto_kernel", side_traffic("crypto", E), N
+    elif args.env in ("cashpenalty", "stoploss"):
         from finrl_amd.vec_cashpenalty import CashPenaltyPanel, VecCashPenaltyEnv, VecStopLossEnv
         T, N, Cc = N_DAYS, N_TICKERS, 5
         close = 50 * np.exp(np.cumsum(rng.normal(0, 0.01, (T, N)), axis=0))
         panel = CashPenaltyPanel(close, rng.normal(0, 10, (T, N, Cc)), np.abs(rng.normal(0, 30, T)))
-        cls = VecCashPenaltyEnv if kind == "cashpenalty" else VecStopLossEnv
-        env = cls(panel, E, hmax=2_000, random_start=True, device=dev)
-        books = 1 if kind == "cashpenalty" else 6
-        # actions + 2 x (cash f64, date/start i32, books f64[N]) + obs + reward/done
-        B = 4 * N + 2 * (16 + 8 * books * N) + 4 * (1 + N + N * Cc) + 5
-        name = f"vectorized {cls.env_name.split('-')[0]} (30 assets x 5 columns, random starts)"
-        kern = f"{kind}_kernel"
-    else:
+        cls = VecCashPenaltyEnv if args.env == "cashpenalty" else VecStopLossEnv
+        w.env = cls(panel, E, hmax=2_000, random_start=True, device=dev, seed=rank)
+        books = 1 if args.env == "cashpenalty" else 6
+        # actions + 2 x (cash f64, date/start i32, books f64[N]) + obs + reward/done, + the per-env
+        # panel row (random starts: close f64[N] + info f32[N*C]) that no broadcast can serve
+        w.B = 4 * N + 2 * (16 + 8 * books * N) + 4 * (1 + N + N * Cc) + 5 + (8 * N + 4 * N * Cc)
+        w.B_note = "4N + 2(16 + 8*books*N) + 4(1+N+NC) + 5 + per-env panel row (8N + 4NC)"
+        nm = cls.env_name.split("-")[0]
+        w.metric = f"env-steps/sec, vectorized {nm} (30 assets x 5 columns, random starts)"
+        w.workload = f"{E} vectorized {nm} per GPU, 30 assets x 5 columns, T={T}, random starts"
+        w.kernel, w.traffic, w.action_dim = f"{args.env}_kernel", side_traffic(args.env, E), N
+    elif args.env == "stocknp":
         from finrl_amd.vec_stocknp import VecStockTradingEnvNP
         T, N, K = N_DAYS, N_TICKERS, N_TECH
         close, tech, risk = synth_panel()
-        env = VecStockTradingEnvNP({"price_array": close, "tech_array": tech.transpose(0, 2, 1)
-                                    .reshape(T, N * K), "turbulence_array": risk * 2,
-                                    "if_train": False}, E, device=dev)
-        B = 4 * N * K + 32 * N + 73                                  # SURVEY 8(d): 1993
-        name, kern = "vectorized array-state StockTradingEnv (DOW30 x 8)", "stocknp_kernel"
-    env.reset()
-    pool = [torch.rand(E, N, device=dev) * 2 - 1 for _ in range(8)]
-    for i in range(args.warmup):
-        env.step(pool[i & 7])
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
+        w.env = VecStockTradingEnvNP({"price_array": close, "tech_array": tech.transpose(0, 2, 1)
+                                      .reshape(T, N * K), "turbulence_array": risk * 2,
+                                      "if_train": False}, E, device=dev)
+        w.B = 4 * N * K + 32 * N + 73                                  # SURVEY 8(d): 1993
+        w.B_note = "4NK + 32N + 73"
+        w.metric = "env-steps/sec, vectorized array-state StockTradingEnv (DOW30 x 8)"
+        w.workload = f"{E} vectorized array-state StockTradingEnv per GPU, DOW30 x 8, T={T}"
+        w.kernel, w.traffic, w.action_dim = "stocknp_kernel", side_traffic("stocknp", E), N
+        w.episode_len = T - 1
+    else:
+        raise ValueError(args.env)
+    w.E = E
+    A = w.action_dim
+    w.pool = [torch.rand(E, A, generator=gen, device=dev) * (1.0 - lo) + lo
+              for _ in range(args.action_pool)]
+    if args.rollout:
+        attach_rollout(w, args, torch, dev, gen)
+    return w
+
+
+def attach_rollout(w, args, torch, dev, gen):
+    """BASELINE configs[4]: PPO rollout collection into device-resident [n_steps, E, .] buffers.
+    Every step writes obs / reward / done straight into slice t (the C ABI takes output pointers:
+    no staging copy), actions / values / log-probs are copied in from a stand-in policy (random
+    tensors: no network is part of the env path), and every n_steps steps the GAE scan kernel runs
+    (finenv_gae_scan).  Still one env step per `step`."""
+    from finrl_amd.rollout import RolloutBuffer
+    n = int(args.rollout)
+    env = w.env
+    D = env.obs.shape[1]
+    buf = RolloutBuffer(n, w.E, D, w.action_dim, device=dev)
+    vals = [torch.rand(w.E, generator=gen, device=dev) for _ in range(4)]
+    lps = [-torch.rand(w.E, generator=gen, device=dev) for _ in range(4)]
+    w.buf = buf
+    w.config_extra = dict(w.config_extra, rollout_n_steps=n,
+                          rollout_bytes=int(sum(t.numel() * t.element_size() for t in
+                                                (buf.obs, buf.actions, buf.rewards, buf.dones,
+                                                 buf.values, buf.log_probs, buf.advantages,
+                                                 buf.returns))))
+    w.workload += f" + PPO rollout collection ({n}-step segments, GAE scan per segment)"
+    # per env-step on top of the env's own bytes: action copy (r+w), value / log-prob (w), and per
+    # segment step the GAE scan's reward / value / done reads and advantage / return writes
+    w.B += 8 * w.action_dim + 8 + (4 + 4 + 1 + 4 + 4)
+    w.B_note += " + rollout: 8A + 8 + 17"
+    state = dict(t=0)
+
+    def step(i):
+        t = state["t"]
+        buf.actions[t].copy_(w.pool[i % len(w.pool)])
+        buf.values[t].copy_(vals[i & 3])
+        buf.log_probs[t].copy_(lps[i & 3])
+        env.step(buf.actions[t], out=(buf.obs[t + 1], buf.rewards[t], buf.dones[t]))
+        t += 1
+        if t == n:
+            buf.compute_returns_and_advantage(vals[i & 3], gamma=0.99, gae_lambda=0.95)
+            buf.obs[0].copy_(buf.obs[n])
+            t = 0
+        state["t"] = t
+
+    def reset():
+        buf.obs[0].copy_(env.reset())
+        state["t"] = 0
+
+    w.step, w.reset = step, reset
+
+
+# ------------------------------------------------------------------------------- timed region
+def timed_region(work, steps, warmup, prewarm, world, dist, sync, make_events, global_envs=None):
+    """prewarm (untimed, then reset) -> warmup (untimed) -> EXACTLY `steps` steps between barrier +
+    synchronize pairs.  Episode ends inside the timed region gather the per-env episode returns
+    over all ranks; when no episode ends there (short runs) ONE gather runs at the end of the
+    region, so every multi-rank run exercises the collective.  Returns wall seconds (max over
+    ranks is taken by the caller), device milliseconds and the rccl record."""
+    from finrl_amd.distributed import gather_episode_returns
+    state = dict(in_ep=0, gathers=0, gathered=0)
+    L = work.episode_len
+
+    def gather():
+        out = gather_episode_returns(work.episode_return(), global_envs)
+        state["gathers"] += 1
+        state["gathered"] = int(out.numel())
+
+    def run(n, timed):
+        for i in range(n):
+            work.step(i)
+            if L is not None:
+                state["in_ep"] += 1
+                if state["in_ep"] == L:
+                    state["in_ep"] = 0
+                    if world > 1 and timed:
+                        gather()
+
+    if prewarm > 0:                       # clock ramp; not part of any reported number
+        run(prewarm, False)
+        sync()
+        run(64, False)                    # short tail: the host comes back from a long blocking wait
+        sync()
+        work.reset()
+        if getattr(work, "after_reset", None):
+            work.after_reset()
+        state["in_ep"] = 0
+    run(warmup, False)
+    ev0, ev1 = make_events()
+    if world > 1:
+        dist.barrier()
+    sync()
     t0 = time.perf_counter()
-    e0.record()
-    for i in range(args.steps):
-        env.step(pool[i & 7])
-    e1.record()
-    torch.cuda.synchronize()
+    ev0.record()
+    run(steps, True)
+    if world > 1 and state["gathers"] == 0:
+        gather()
+    ev1.record()
+    sync()
+    if world > 1:
+        dist.barrier()
     wall = time.perf_counter() - t0
-    per = e0.elapsed_time(e1) * 1e-3 / args.steps
-    ach = B * E / per / 1e9
-    print(json.dumps({
-        "metric": f"env-steps/sec, {name}", "value": E * args.steps / wall,
-        "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{E} {name}", "envs_per_gpu": E},
-        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBS, "traffic": side_traffic(kind, E), "kernel": kern,
-                     "bytes_per_env_step": B, "avg_launch_us": per * 1e6}}), flush=True)
+    rccl = None
+    if world > 1:
+        rccl = dict(world=world, backend=dist.get_backend(), gathers=state["gathers"],
+                    gathered=state["gathered"])
+    return wall, ev0.elapsed_time(ev1), rccl
 
 
 def main():
@@ -268,6 +452,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3 * N_DAYS)
     ap.add_argument("--warmup", type=int, default=N_DAYS)
+    ap.add_argument("--prewarm", type=int, default=None,
+                    help="untimed launches before --warmup (clock ramp), followed by a reset; "
+                         f"default {PREWARM_DEFAULT} when --warmup < 1024, else 0")
     ap.add_argument("--envs-per-gpu", type=int, default=E_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stats", action="store_true", help="disable on-device Sharpe stats")
@@ -278,13 +465,13 @@ def main():
                     help="30 = DOW30 (headline); 100 = NASDAQ-100 shape (BASELINE configs[3])")
     ap.add_argument("--turbulence-pct", type=float, default=None,
                     help="turbulence_threshold = this percentile of the synthetic risk series")
+    ap.add_argument("--rollout", type=int, default=0,
+                    help="collect into [n_steps, E, .] rollout buffers + GAE scan per segment "
+                         "(BASELINE configs[4])")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from finrl_amd import StockPanel
-    from finrl_amd.distributed import gather_episode_returns
-    from finrl_amd.vec_env import VecStockTradingEnv
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -295,103 +482,60 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
-    if args.env == "portfolio":
-        assert world == 1, "portfolio side-bench is single-GPU"
-        return bench_portfolio(args, torch, dev)
-    if args.env in ("crypto", "stocknp", "cashpenalty", "stoploss"):
-        assert world == 1, "side benches are single-GPU"
-        return bench_side(args, torch, dev, args.env)
+    prewarm = args.prewarm if args.prewarm is not None else \
+        (PREWARM_DEFAULT if args.warmup < 1024 else 0)
 
-    E, N, K, T = args.envs_per_gpu, args.tickers, N_TECH, N_DAYS
-    close, tech, risk = synth_panel(N=N)
-    thr = None if args.turbulence_pct is None else float(np.percentile(risk, args.turbulence_pct))
-    env = VecStockTradingEnv(StockPanel(close, tech, risk), E, device=dev,
-                             track_stats=not args.no_stats, auto_reset=True,
-                             turbulence_threshold=thr, **ENV_KW)
-    env.reset()
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    pool = [torch.rand(E, N, generator=gen, device=dev) * 2 - 1 for _ in range(args.action_pool)]
-    if args.desync:     # walk every env to a random day by masked resets at random steps
-        offs = torch.randint(0, T - 1, (E,), generator=gen, device=dev)
-        env.state["day"].copy_(offs.to(torch.int32))
-        env.state["price_day"].copy_(offs.to(torch.int32))
+    work = build_workload(args, torch, dev, rank)
+    work.reset()
+    if getattr(work, "after_reset", None):
+        work.after_reset()
 
-    gathered = None
-    step_in_ep = 0
+    def make_events():
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    def run(n):
-        nonlocal step_in_ep, gathered
-        for i in range(n):
-            env.step(pool[i % len(pool)])
-            step_in_ep += 1
-            if world > 1 and not args.desync and step_in_ep == T:
-                # episode end on every rank: gather per-env episode returns (RCCL, 256 KB/rank)
-                gathered = gather_episode_returns(env.episode_return(), world * E)
-            if step_in_ep == T:
-                step_in_ep = 0
-
-    run(args.warmup)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev0.record()
-    run(args.steps)
-    ev1.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
+    wall, dev_ms, rccl = timed_region(work, args.steps, args.warmup, prewarm, world, dist,
+                                      torch.cuda.synchronize, make_events,
+                                      global_envs=world * work.E)
     if world > 1:
         tt = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
 
     if rank == 0:
-        B = algorithmic_bytes(N, K)
+        E = work.E
         per_launch_s = dev_ms * 1e-3 / args.steps        # HIP events on the launch stream
-        achieved = B * E / per_launch_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("envs_per_gpu") == E and tj.get("kernel") == "stock_step" and \
-                        tj.get("tickers") == N and thr is None:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        achieved = work.B * E / per_launch_s / 1e9
         out = {
-            "metric": ("env-steps/sec at N parallel envs (DOW30, 8 indicators)" if N == 30 else
-                       f"env-steps/sec at N parallel envs ({N} tickers, 8 indicators)"),
+            "metric": work.metric,
             "value": world * E * args.steps / wall,
             "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{E} vectorized StockTradingEnv per GPU, "
-                                   + ("DOW30" if N == 30 else f"{N} tickers") +
-                                   f" x 8 indicators, T={T}, random actions"
-                                   + (f", turbulence threshold p{args.turbulence_pct:g}" if thr is not None else "")
-                                   + (", desynchronised start days" if args.desync else ""),
-                       "envs_per_gpu": E, "global_envs": world * E, "tickers": N,
-                       "indicators": K, "days": T, "track_stats": not args.no_stats,
-                       "parallelism": f"env-shard x{world}"},
+            "prewarm_launches": prewarm,
+            "config": dict({"workload": work.workload, "envs_per_gpu": E,
+                            "global_envs": world * E, "parallelism": f"env-shard x{world}"},
+                           **work.config_extra),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "stock_step_kernel", "bytes_per_env_step": B,
-                         "avg_launch_us": per_launch_s * 1e6},
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": work.traffic,
+                         "kernel": work.kernel, "bytes_per_env_step": work.B,
+                         "bytes_formula": work.B_note, "avg_launch_us": per_launch_s * 1e6},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if rccl is not None:
+            out["rccl"] = rccl
+        if world == 1 and not args.no_cpu_baseline and args.env == "stock" and \
+                args.tickers == N_TICKERS and not args.desync:
+            close, tech, risk = work.panel_arrays
             out["cpu_baseline"] = cpu_baseline(close, tech, risk)
             out["cpu_baseline"]["parity_sample"] = parity_sample(close, tech, risk, dev)
             nthr = max(1, min(16, len(os.sched_getaffinity(0))))    # the box's CPU share for one GPU
             if nthr > 1:
                 out["cpu_baseline_all_cores"] = cpu_baseline_threads(close, tech, risk, nthr)
+            try:
+                out["cpu_baseline_python"] = cpu_baseline_python(close, tech, risk)
+            except ImportError:
+                pass
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -24,25 +24,49 @@ def shard_range(global_envs: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+# constructor arguments that may be given per env ([E] / [E, N]) and are then sliced per rank
+_PER_ENV_KWARGS = ("initial_amount", "num_stock_shares", "initial_capital", "initial_stocks")
+
+
 def shard_env_kwargs(global_envs: int, rank: int, world: int, **kw):
-    """Slice per-env constructor arguments (initial_amount [E], num_stock_shares [E, N]) down
+    """Slice per-env constructor arguments (e.g. initial_amount [E], num_stock_shares [E, N]) down
     to this rank's envs; scalars / per-ticker vectors pass through unchanged."""
     lo, hi = shard_range(global_envs, rank, world)
     out = dict(kw)
-    ia = kw.get("initial_amount")
-    if ia is not None and np.ndim(ia) == 1 and len(ia) == global_envs:
-        out["initial_amount"] = np.asarray(ia)[lo:hi]
-    ns = kw.get("num_stock_shares")
-    if ns is not None and np.ndim(ns) == 2 and len(ns) == global_envs:
-        out["num_stock_shares"] = np.asarray(ns)[lo:hi]
+    for name in _PER_ENV_KWARGS:
+        v = kw.get(name)
+        if v is not None and np.ndim(v) >= 1 and len(v) == global_envs and \
+                (np.ndim(v) == 2 or name in ("initial_amount", "initial_capital")):
+            out[name] = np.asarray(v)[lo:hi]
     return hi - lo, out
 
 
-def make_sharded_env(panel, global_envs: int, *, rank=None, world=None, device=None, **kw):
-    """This rank's VecStockTradingEnv shard (panel replicated on the local GPU)."""
+def env_class(kind):
+    """Batched env class by name: every env of SURVEY.md 8(a)/(f-3) shards the same way."""
+    if kind == "stock":
+        from .vec_env import VecStockTradingEnv as cls
+    elif kind == "stocknp":
+        from .vec_stocknp import VecStockTradingEnvNP as cls
+    elif kind == "portfolio":
+        from .vec_portfolio import VecStockPortfolioEnv as cls
+    elif kind == "crypto":
+        from .vec_crypto import VecCryptoEnv as cls
+    elif kind == "cashpenalty":
+        from .vec_cashpenalty import VecCashPenaltyEnv as cls
+    elif kind == "stoploss":
+        from .vec_cashpenalty import VecStopLossEnv as cls
+    else:
+        raise ValueError(f"unknown env kind {kind!r}")
+    return cls
+
+
+def make_sharded_env(panel, global_envs: int, *, kind="stock", rank=None, world=None,
+                     device=None, **kw):
+    """This rank's shard of a global batch of `kind` envs (market panel / config replicated on the
+    local GPU).  `panel` is whatever the env class takes first: a StockPanel / PortfolioPanel /
+    CashPenaltyPanel, or the reference-style config dict of the array-state and crypto envs."""
     import torch
     import torch.distributed as dist
-    from .vec_env import VecStockTradingEnv
     if rank is None:
         rank = dist.get_rank() if dist.is_initialized() else 0
     if world is None:
@@ -50,16 +74,19 @@ def make_sharded_env(panel, global_envs: int, *, rank=None, world=None, device=N
     n_local, kw = shard_env_kwargs(global_envs, rank, world, **kw)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    return VecStockTradingEnv(panel, n_local, device=device, **kw)
+    return env_class(kind)(panel, n_local, device=device, **kw)
 
 
 def gather_episode_returns(local_returns, global_envs: int = None, group=None):
     """All-gather the per-env episode returns of every rank into global env order.
 
     local_returns: 1-D tensor (this rank's envs, in local order).  Returns a 1-D tensor of
-    length sum(shard sizes) on the same device, identical on every rank.  Equal shard sizes
-    use one `all_gather_into_tensor` (a single RCCL all-gather); ragged shards fall back to
-    the list form.
+    length sum(shard sizes) on the same device, identical on every rank.  Which collective runs
+    is decided by ARITHMETIC that every rank evaluates identically (never by catching an error on
+    one rank, which would leave the ranks in different collectives): equal shards -- global_envs
+    omitted or divisible by the world size -- use one `all_gather_into_tensor` (a single RCCL
+    all-gather; gloo implements it too); ragged shards pad to the largest shard and use the list
+    form.
     """
     import torch
     import torch.distributed as dist
@@ -67,15 +94,13 @@ def gather_episode_returns(local_returns, global_envs: int = None, group=None):
         return local_returns.clone()
     world = dist.get_world_size(group)
     n = local_returns.numel()
-    if global_envs is None or global_envs == n * world:
+    if global_envs is None or global_envs % world == 0:
+        if global_envs is not None and n * world != global_envs:
+            raise ValueError(f"rank holds {n} envs, expected {global_envs // world}")
         out = torch.empty(n * world, dtype=local_returns.dtype, device=local_returns.device)
-        try:
-            dist.all_gather_into_tensor(out, local_returns.contiguous(), group=group)
-            return out
-        except (RuntimeError, NotImplementedError):
-            pass
-    sizes = [shard_range(global_envs if global_envs is not None else n * world, r, world)
-             for r in range(world)]
+        dist.all_gather_into_tensor(out, local_returns.contiguous(), group=group)
+        return out
+    sizes = [shard_range(global_envs, r, world) for r in range(world)]
     nmax = max(hi - lo for lo, hi in sizes)
     pad = torch.zeros(nmax, dtype=local_returns.dtype, device=local_returns.device)
     pad[:n] = local_returns

@@ -188,6 +188,11 @@ class VecCashPenaltyEnv:
         from .vec_env import SB3VecEnvAdapter
         return SB3VecEnvAdapter(self)
 
+    def episode_return(self):
+        """last logged total assets / initial amount per env (the GainLoss figure, :176), f32."""
+        import torch
+        return (self.state["logged_total"] / float(self._cfg.initial_amount)).to(torch.float32)
+
     def state_numpy(self):
         out = {k: v.detach().cpu().numpy() for k, v in self.state.items()}
         for k in self._books:

@@ -134,6 +134,11 @@ class VecCryptoEnv:
         from .vec_env import SB3VecEnvAdapter
         return SB3VecEnvAdapter(self)
 
+    def episode_return(self):
+        """total_asset / initial cash of each env's last finished episode (:89), f32."""
+        import torch
+        return self.state["episode_return"].to(torch.float32)
+
     def state_numpy(self):
         out = {k: v.detach().cpu().numpy() for k, v in self.state.items()}
         out["stocks"] = np.ascontiguousarray(out["stocks"].T)

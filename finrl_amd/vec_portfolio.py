@@ -110,5 +110,10 @@ class VecStockPortfolioEnv:
         from .vec_env import SB3VecEnvAdapter
         return SB3VecEnvAdapter(self)
 
+    def episode_return(self):
+        """portfolio value / initial amount per env, f32 (the quantity gathered across ranks)."""
+        import torch
+        return (self.state["value"] / float(self._cfg.initial_amount)).to(torch.float32)
+
     def state_numpy(self):
         return {k: v.detach().cpu().numpy() for k, v in self.state.items()}

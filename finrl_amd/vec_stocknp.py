@@ -174,6 +174,11 @@ class VecStockTradingEnvNP:
         from .vec_env import SB3VecEnvAdapter
         return SB3VecEnvAdapter(self)
 
+    def episode_return(self):
+        """total_asset / initial_total_asset of each env's last finished episode (:145), f32."""
+        import torch
+        return self.state["episode_return"].to(torch.float32)
+
     def state_numpy(self):
         out = {k: v.detach().cpu().numpy() for k, v in self.state.items()}
         for k in ("stocks", "cool_down", "stocks0"):

@@ -70,3 +70,90 @@ def test_gather_episode_returns_gloo(world, global_envs):
         assert st["count"] == global_envs
         assert st["min"] == expect.min() and st["max"] == expect.max()
         assert abs(st["mean"] - expect.mean()) < 1e-9
+
+
+# ---------------------------------------------------------------------------------------------
+# bench.py's timed region over gloo: the collective runs inside the timed region at every episode
+# end -- and once at its end when no episode finished there -- and the JSON `rccl` block reports
+# how many ranks took part.  A CPU stand-in implements the Workload protocol (the envs themselves
+# have no CPU path).
+# ---------------------------------------------------------------------------------------------
+class _StubWork:
+    def __init__(self, lo, hi, episode_len):
+        self.lo, self.hi, self.episode_len = lo, hi, episode_len
+        self.n_steps = self.n_resets = 0
+
+    def step(self, i):
+        self.n_steps += 1
+
+    def reset(self):
+        self.n_resets += 1
+
+    def episode_return(self):
+        return torch.arange(self.lo, self.hi, dtype=torch.float32) + 0.25 * self.n_steps
+
+
+class _Ev:
+    def record(self):
+        self.t = 0.0
+
+    def elapsed_time(self, other):
+        return 1.0
+
+
+def _bench_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = []
+    for steps, warmup, prewarm, L in [(3, 2, 0, 5), (2, 2, 0, 5), (12, 1, 7, 5), (4, 0, 0, None)]:
+        lo, hi = shard_range(64, rank, world)
+        w = _StubWork(lo, hi, L)
+        wall, dev_ms, rccl = bench.timed_region(w, steps, warmup, prewarm, world, dist,
+                                                lambda: None, lambda: (_Ev(), _Ev()),
+                                                global_envs=64)
+        res.append((steps, warmup, prewarm, L, w.n_steps, w.n_resets, rccl))
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_timed_region_gathers_over_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        (a, b, c, d) = out[rank]
+        # episode of 5 steps ends exactly at the last timed step: one gather, at the episode end
+        assert a[4] == 5 and a[6] == dict(world=2, backend="gloo", gathers=1, gathered=64)
+        # no episode end inside the timed region: one gather at its end all the same
+        assert b[6]["gathers"] == 1 and b[6]["gathered"] == 64
+        # prewarm (7 + 64 launches) is followed by a reset and does not count; 12 timed steps after
+        # 1 warm-up step cross two episode ends
+        assert c[4] == 7 + 64 + 1 + 12 and c[5] == 1 and c[6]["gathers"] == 2
+        # envs without a common episode length: the single end-of-region gather
+        assert d[6]["gathers"] == 1
+
+
+def test_every_env_kind_shards():
+    from finrl_amd.distributed import env_class
+    for kind, name in [("stock", "VecStockTradingEnv"), ("stocknp", "VecStockTradingEnvNP"),
+                       ("portfolio", "VecStockPortfolioEnv"), ("crypto", "VecCryptoEnv"),
+                       ("cashpenalty", "VecCashPenaltyEnv"), ("stoploss", "VecStopLossEnv")]:
+        cls = env_class(kind)
+        assert cls.__name__ == name and hasattr(cls, "episode_return") and hasattr(cls, "step")
+    with pytest.raises(ValueError):
+        env_class("nope")
+    n, kw = shard_env_kwargs(10, 2, 3, initial_capital=np.arange(10.0), gamma=0.9)
+    assert n == 3 and kw["gamma"] == 0.9
+    np.testing.assert_array_equal(kw["initial_capital"], np.arange(10.0)[7:10])
