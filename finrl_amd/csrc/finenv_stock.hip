@@ -119,8 +119,9 @@ int launch_step(finenv_stock *h, const Params &p, bool turb, bool stats, hipStre
 }  // namespace
 
 #ifdef FINENV_DIAG
-static unsigned long long *g_dbg = nullptr;
-extern "C" void finenv_diag_set_stamp_buffer(void *ptr) { g_dbg = (unsigned long long *)ptr; }
+unsigned long long *g_finenv_dbg = nullptr;      // shared with the other kernels' diagnostic builds
+#define g_dbg g_finenv_dbg
+extern "C" void finenv_diag_set_stamp_buffer(void *ptr) { g_finenv_dbg = (unsigned long long *)ptr; }
 #endif
 
 extern "C" {

@@ -59,7 +59,12 @@ def test_crypto_hip_matches_reference_fixture(name):
 @pytest.mark.parametrize("cfg", [dict(E=1000, T=40, N=10, W=40, L=1, steps=90),
                                  dict(E=130, T=25, N=3, W=7, L=3, steps=60),
                                  dict(E=65, T=16, N=32, W=1, L=2, steps=40),
-                                 dict(E=64, T=12, N=1, W=0, L=1, steps=30)])
+                                 dict(E=64, T=12, N=1, W=0, L=1, steps=30),
+                                 # padded-width boundaries (8 / 16 / 32-wide builds) and the
+                                 # observation block path: D = 64 (even), D = 65 (row-wise path)
+                                 dict(E=200, T=20, N=17, W=5, L=1, steps=45),
+                                 dict(E=128, T=20, N=16, W=47, L=1, steps=45),
+                                 dict(E=70, T=20, N=8, W=56, L=1, steps=45)])
 def test_crypto_hip_matches_oracle_random_batch(cfg):
     _need_gpu()
     from finrl_amd.vec_crypto import VecCryptoEnv
