@@ -19,6 +19,10 @@
 #include "finenv_dev.h"
 #include "finenv_host.h"
 
+#ifdef FINENV_DIAG
+extern unsigned long long *g_finenv_dbg;         // finenv_stock.hip (diagnostic builds)
+#endif
+
 namespace {
 
 constexpr int kWave = 64;
@@ -41,7 +45,21 @@ struct NpParams {
     int32_t auto_reset;
     int32_t D;
     uint32_t magicN;
+    unsigned long long *dbg;      // FINENV_DIAG builds only: [wave][16] s_memrealtime stamps
 };
+
+#ifdef FINENV_DIAG
+#define NSTAMP(k)                                                                           \
+    do {                                                                                    \
+        if (p.dbg != nullptr && lane == 0) {                                                \
+            __builtin_amdgcn_sched_barrier(0);                                              \
+            p.dbg[(size_t)(e0 / kWave) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();      \
+            __builtin_amdgcn_sched_barrier(0);                                              \
+        }                                                                                   \
+    } while (0)
+#else
+#define NSTAMP(k) do { } while (0)
+#endif
 
 #define NF(fld) (*at(p.st.f64, (unsigned)(fld) * (unsigned)E + (unsigned)e))
 #define NI(fld) (*at(p.st.i32, (unsigned)(fld) * (unsigned)E + (unsigned)e))
@@ -231,6 +249,7 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
     }
 
     const int kpatch = (2 + 3 * N) / kWave + 1;            // chunks that hold amount / stocks / cool_down
+    if (role == 0) NSTAMP(0);
     if (role == 1) {
         int day_s = NI(FINENV_NI_DAY) + 1;
         // the day counter is read (and has arrived) before the block-wide barrier; the traders
@@ -242,7 +261,9 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
         if (dm != 0ull && p.term_obs != nullptr)
             np_write_rows<true>(p.term_obs, p, e0, nenv_w, day_s, dm, heads, lane, kpatch);
         const int rd = (done_s && p.auto_reset) ? 0 : day_s;
+        NSTAMP(9);
         np_write_rows(p.obs, p, e0, nenv_w, rd, vm, heads, lane, kpatch);
+        NSTAMP(10);
         return;
     }
     // ---- action tile -> LDS rows (stride kRowA inside the heads region) ---------------------
@@ -279,6 +300,7 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
         }
     }
     wave_sync();
+    NSTAMP(1);
     const float *arow = heads + lane * kRowA;
     const float ms = (float)p.cfg.max_stock;
     const Num one_m = mk(1 - p.cfg.sell_cost_pct, FINENV_NT_PY);
@@ -429,6 +451,7 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
             }
         }
     }
+    NSTAMP(2);
     if (!calm) {
         const Num t0 = mk((double)holdings_value(scol, p.panel.price, pb, N, prow), FINENV_NT_F32);
         amount = n_add(amount, n_mul(t0, one_m));
@@ -451,6 +474,7 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
         *at(p.done, (unsigned)e) = done ? 1 : 0;
         NF(FINENV_NF_LAST_REWARD) = r.v;
     }
+    NSTAMP(3);
     wave_sync();
     fill_head(amount);                       // overwrites the (consumed) action rows
     wave_sync();
@@ -470,8 +494,11 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
             wave_sync();
         }
     }
+    NSTAMP(4);
     np_write_rows(p.obs, p, e0, nenv_w, row_day, valid_mask, heads, lane, 0, kpatch);
+    NSTAMP(5);
     if (valid) store_state(amount, ta, gr, ita, r.tag, row_day);
+    NSTAMP(6);
 }
 
 }  // namespace
@@ -591,6 +618,9 @@ int finenv_stocknp_step(finenv_stocknp *h, const float *actions, float *obs, flo
     p.done = done;
     p.term_obs = term_obs;
     p.auto_reset = auto_reset;
+#ifdef FINENV_DIAG
+    p.dbg = g_finenv_dbg;
+#endif
     hipLaunchKernelGGL((stocknp_kernel<false>), np_grid(h->cfg.n_envs), dim3(kWave * kWaves * 2), 0,
                        (hipStream_t)stream, p);
     return np_check(h, "stocknp_step");
