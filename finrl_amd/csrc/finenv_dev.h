@@ -240,4 +240,90 @@ __device__ __forceinline__ void write_obs_rows_generic(float *__restrict__ dst,
     }
 }
 
+// -------------------------------------------------------------------------------------
+// The observation chunks that hold cash / holdings columns ("head" chunks, k < KP), lock-step days:
+// written after the hand-off barrier, half the rows by each wave.  Their template (market data)
+// values must NOT be loaded from global memory at that point: a load issued after stores waits until
+// every older store of the wave is acknowledged (vmcnt retires in order; 2-4 us for a streamer with
+// a few hundred stores in flight), pinning or `volatile` loads at the start of the streamer cost a
+// round trip before its first store (measured: +0.7 / +2.3 us).  So the wave that waits for global
+// data anyway at the start of the step (it stages the price row) also fetches these KP values per
+// lane and parks them in LDS (head_stage); after the barrier both waves read them back (head_plan).
+//   widx(col)     -> index of the per-env value of that column in the caller's LDS image, or -1
+//                    (market data: the template value is written)
+//   val(el, w)    -> that value of env el as f32
+// -------------------------------------------------------------------------------------
+template <int KP>
+struct HeadPlan {
+    float t[KP];
+    int w[KP];
+    bool in[KP];
+    bool uniform;            // every selected env reads the same panel row (else: generic writer)
+};
+
+// issue the KP template loads (values for the caller to hold until it calls head_park)
+template <int KP>
+__device__ __forceinline__ void head_fetch(float (&tt)[KP], const float *__restrict__ tmpl, int D,
+                                           int row_first, int lane, int kp)
+{
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        const int col = k * kWaveSize + lane;
+        tt[k] = *at(tmpl, (unsigned)(row_first * D + ((k < kp && col < D) ? col : 0)));
+    }
+}
+
+template <int KP>
+__device__ __forceinline__ void head_park(float *ldst, const float (&tt)[KP], int lane)
+{
+#pragma unroll
+    for (int k = 0; k < KP; ++k) ldst[k * kWaveSize + lane] = tt[k];
+}
+
+template <int KP, typename WIdx>
+__device__ __forceinline__ void head_plan(HeadPlan<KP> &hp, const float *ldst, int D, int row_day,
+                                          int row_first, unsigned long long lane_mask, int lane,
+                                          int kp, WIdx widx)
+{
+    const bool mine = (lane_mask >> lane) & 1ull;
+    hp.uniform = __all(!mine || row_day == row_first);
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        const int col = k * kWaveSize + lane;
+        hp.in[k] = k < kp && col < D;
+        hp.w[k] = hp.in[k] ? widx(col) : -1;
+        hp.t[k] = ldst[k * kWaveSize + lane];
+    }
+}
+
+template <int KP, typename Val>
+__device__ __forceinline__ void head_store(const HeadPlan<KP> &hp, float *__restrict__ dst, int D,
+                                           int e0, int nenv_w, unsigned long long lane_mask,
+                                           int lane, int el_lo, int el_hi, Val val)
+{
+    float *const base = dst + (size_t)e0 * D;
+    const int hi = min(nenv_w, el_hi);
+    // batches of kB rows: the batch's LDS reads are all in flight before its first store (one row
+    // at a time exposes an LDS round trip per row: ~170 cycles x 64 rows at the tail of every block)
+    constexpr int kB = KP <= 2 ? 8 : 4;
+    for (int g = el_lo; g < hi; g += kB) {
+        float pv[kB][KP];
+#pragma unroll
+        for (int j = 0; j < kB; ++j)
+#pragma unroll
+            for (int k = 0; k < KP; ++k) pv[j][k] = val(min(g + j, kWaveSize - 1), hp.w[k] >= 0 ? hp.w[k] : 0);
+#pragma unroll
+        for (int j = 0; j < kB; ++j) {
+            const int el = g + j;
+            if (el >= hi || !((lane_mask >> el) & 1ull)) continue;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const float v = hp.w[k] >= 0 ? pv[j][k] : hp.t[k];
+                if (hp.in[k]) *at(base, (unsigned)(el * D + k * kWaveSize + lane)) = v;
+            }
+        }
+    }
+}
+
+
 }  // namespace

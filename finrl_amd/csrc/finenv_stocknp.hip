@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -30,7 +31,9 @@ constexpr int kMaxN = FINENV_STOCKNP_MAX_TICKERS;
 constexpr int kRowA = kMaxN + 1;                       // action rows, stride 33
 constexpr int kRowH = 2 * kMaxN + 1;                   // obs heads [amount|stocks|cool], stride 65
 constexpr int kWaves = 4;
-constexpr int kLdsPerWave = kWave * kRowH + 2 * kMaxN * kWave + kMaxN;   // heads/actions + stocks + cool + price row
+constexpr int kHeadMax = (2 + 3 * kMaxN) / kWave + 1;  // observation chunks holding per-env columns
+// heads/actions + stocks + cool + price row + parked head-chunk template values
+constexpr int kLdsPerWave = kWave * kRowH + 2 * kMaxN * kWave + kMaxN + kHeadMax * kWave;
 
 struct NpParams {
     finenv_stocknp_config cfg;
@@ -46,6 +49,7 @@ struct NpParams {
     int32_t D;
     uint32_t magicN;
     unsigned long long *dbg;      // FINENV_DIAG builds only: [wave][16] s_memrealtime stamps
+    int32_t diag;                 // FINENV_DIAG builds only: experiment switches (env FINENV_DIAG)
 };
 
 #ifdef FINENV_DIAG
@@ -57,8 +61,10 @@ struct NpParams {
             __builtin_amdgcn_sched_barrier(0);                                              \
         }                                                                                   \
     } while (0)
+#define NDIAG(bit) (p.diag & (bit))
 #else
 #define NSTAMP(k) do { } while (0)
+#define NDIAG(bit) 0
 #endif
 
 #define NF(fld) (*at(p.st.f64, (unsigned)(fld) * (unsigned)E + (unsigned)e))
@@ -204,6 +210,7 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
     float *scol = stk + lane, *ccol = cdl + lane;
     float *head = heads + lane * kRowH;
     float *prow_lds = cdl + kMaxN * kWave;                 // [ticker] shared price row (lock-step days)
+    float *ldshead = prow_lds + kMaxN;                     // [chunk][lane] head-chunk template values
 
     // reset(): day 0, start state, total_asset = amount + (stocks*price[0]).sum()  (:80-101)
     auto do_reset = [&](Num &amount, Num &ta, Num &gr, Num &ita) {
@@ -249,6 +256,11 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
     }
 
     const int kpatch = (2 + 3 * N) / kWave + 1;            // chunks that hold amount / stocks / cool_down
+    // column -> index into heads[el * kRowH + .] (amount | stocks | cool_down), or -1 (market data)
+    auto head_widx = [N](int col) {
+        const int hidx = col - 3 - N;
+        return col == 0 ? 0 : ((hidx >= 0 && hidx < 2 * N) ? 1 + hidx : -1);
+    };
     if (role == 0) NSTAMP(0);
     if (role == 1) {
         int day_s = NI(FINENV_NI_DAY) + 1;
@@ -264,6 +276,21 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
         NSTAMP(9);
         np_write_rows(p.obs, p, e0, nenv_w, rd, vm, heads, lane, kpatch);
         NSTAMP(10);
+        // hand-off: once the traders have published amount / stocks / cool-downs in LDS, this wave
+        // writes the upper half of the rows of the chunks that hold them (the trader the lower
+        // half).  Episode-end steps keep that write in the trader.
+        lds_barrier();
+        if (dm == 0ull && !NDIAG(1)) {
+            HeadPlan<kHeadMax> hp;
+            head_plan(hp, ldshead, p.D, rd, __builtin_amdgcn_readfirstlane(rd), vm, lane, kpatch,
+                      head_widx);
+            if (hp.uniform)
+                head_store(hp, p.obs, p.D, e0, nenv_w, vm, lane, kWave / 2, kWave,
+                           [heads](int el, int w) { return heads[el * kRowH + w]; });
+            else
+                np_write_rows(p.obs, p, e0, nenv_w, rd, vm & 0xFFFFFFFF00000000ull, heads, lane, 0,
+                              kpatch);
+        }
         return;
     }
     // ---- action tile -> LDS rows (stride kRowA inside the heads region) ---------------------
@@ -281,6 +308,11 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
     if (uni && lane < kMaxN)
         prow_lds[lane] = *at(p.panel.price, (unsigned)(day0 * N + min(lane, N - 1)));
     const float *prow = uni ? prow_lds : nullptr;
+    // market-data values of the head chunks of the NEXT observation (row `day`), fetched now --
+    // the trader has no stores in flight yet -- and parked in LDS before the hand-off barrier: a
+    // global load issued after the streamers' stores waits behind them (13 us measured here)
+    float head_tt[kHeadMax];
+    head_fetch(head_tt, p.panel.obs_tmpl, p.D, day0, lane, kpatch);
     // (global loads in batches, issued before their first use: a rolled loop exposes one HBM round
     //  trip per ticker at one wave per SIMD)
     for (int i0 = 0; i0 < N; i0 += 16) {
@@ -316,70 +348,78 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
     // computed, tag-selected) is most of this kernel's arithmetic; any other tag mix takes the
     // generic loops below.  Same operations, same order, same roundings in both.
     if (__all(amount.tag == FINENV_NT_F64)) {
+        // Statically indexed registers, branch-free per ticker (selects), reciprocals of the prices
+        // computed off the cash chain: the first form kept stocks / cool-downs / actions in LDS and
+        // paid an LDS round trip inside every divergent per-ticker block (10.4 us of a 34 us step).
         double amt = amount.v;
-        for (int i0 = 0; i0 < N; i0 += kPB) {
-            float prb[kPB];
+        float sr[kMaxN], cr[kMaxN], pr_[kMaxN];
+        int ai[kMaxN];
 #pragma unroll
-            for (int j = 0; j < kPB; ++j) prb[j] = 0.0f;
-            if (uni) {                       // (a branch, not a select: no global load at all)
-#pragma unroll
-                for (int j = 0; j < kPB; ++j) prb[j] = prow_lds[min(i0 + j, N - 1)];
-            } else {
-#pragma unroll
-                for (int j = 0; j < kPB; ++j)
-                    prb[j] = *at(p.panel.price, pb + (unsigned)min(i0 + j, N - 1));
-            }
-#pragma unroll
-            for (int j = 0; j < kPB; ++j) pin(prb[j]);
-#pragma unroll
-            for (int j = 0; j < kPB; ++j) {
-                const int i = i0 + j;
-                if (i >= N) break;
-                const int a = (int)(arow[i] * ms);                                // :104
-                const float pr = prb[j];
-                if (calm && a < -min_action && pr > 0.0f) {
-                    const float s = scol[i * kWave];
-                    const double want = (double)(-a);
-                    const bool is_int = want < (double)s;        // min(stocks, -a) -> -a (np.int64)
-                    const double sell = is_int ? want : (double)s;
-                    scol[i * kWave] = (float)((double)s - sell);
-                    // int64 share count: float64 product chain; float32 count: float32 chain
-                    const double term = is_int ? ((double)pr * sell) * one_m.v
-                                               : (double)((pr * (float)sell) * (float)one_m.v);
-                    amt = amt + term;
-                    ccol[i * kWave] = 0.0f;
-                }
-            }
+        for (int i = 0; i < kMaxN; ++i) {
+            const int ic = min(i, N - 1);
+            sr[i] = scol[ic * kWave];
+            cr[i] = ccol[ic * kWave];
+            ai[i] = (int)(arow[ic] * ms);                                         // :104
+            pr_[i] = 0.0f;
         }
-        for (int i0 = 0; i0 < N; i0 += kPB) {
-            float prb[kPB];
+        if (uni) {                           // (a branch, not a select: no global load at all)
 #pragma unroll
-            for (int j = 0; j < kPB; ++j) prb[j] = 0.0f;
-            if (uni) {                       // (a branch, not a select: no global load at all)
+            for (int i = 0; i < kMaxN; ++i) pr_[i] = prow_lds[min(i, N - 1)];
+        } else {
 #pragma unroll
-                for (int j = 0; j < kPB; ++j) prb[j] = prow_lds[min(i0 + j, N - 1)];
-            } else {
+            for (int i = 0; i < kMaxN; ++i) pr_[i] = *at(p.panel.price, pb + (unsigned)min(i, N - 1));
+        }
 #pragma unroll
-                for (int j = 0; j < kPB; ++j)
-                    prb[j] = *at(p.panel.price, pb + (unsigned)min(i0 + j, N - 1));
+        for (int i = 0; i < kMaxN; ++i) {                                         // sells :112-119
+            if (i >= N) continue;             // (continue, not break: keeps the loop fully unrollable)
+            const int a = ai[i];
+            const float pr = pr_[i];
+            const bool ok = calm && a < -min_action && pr > 0.0f;
+            const float s = sr[i];
+            const double want = (double)(-a);
+            const bool is_int = want < (double)s;            // min(stocks, -a) -> -a (np.int64)
+            const double sell = is_int ? want : (double)s;
+            const float s_new = (float)((double)s - sell);
+            // int64 share count: float64 product chain; float32 count: float32 chain
+            const double t64 = ((double)pr * sell) * one_m.v;
+            const double t32 = (double)((pr * (float)sell) * (float)one_m.v);
+            const double amt_new = amt + (is_int ? t64 : t32);
+            sr[i] = ok ? s_new : s;
+            cr[i] = ok ? 0.0f : cr[i];
+            amt = ok ? amt_new : amt;
+        }
+        double xr[kMaxN];
+#pragma unroll
+        for (int i = 0; i < kMaxN; ++i) {
+            const double d = (double)pr_[i];
+            const double x = __builtin_amdgcn_rcp(d);
+            xr[i] = fma(fma(-d, x, 1.0), x, x);
+        }
+#pragma unroll
+        for (int i = 0; i < kMaxN; ++i) {                                         // buys :120-129
+            if (i >= N) continue;
+            const int a = ai[i];
+            const double d = (double)pr_[i];
+            const bool ok = calm && a > min_action && pr_[i] > 0.0f;
+            double q = floor(amt * xr[i]);                                        // amount // price
+            double r = fma(-q, d, amt);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {     // (floordiv_true with the reciprocal hoisted)
+                q += (r < 0.0) ? -1.0 : ((r >= d) ? 1.0 : 0.0);
+                r = fma(-q, d, amt);
             }
+            const double buy = ((double)a < q) ? (double)a : q;                   // min(q, a)
+            const float s_new = (float)((double)sr[i] + buy);
+            const double amt_new = amt - ((d * buy) * one_p.v);
+            sr[i] = ok ? s_new : sr[i];
+            cr[i] = ok ? 0.0f : cr[i];
+            amt = ok ? amt_new : amt;
+        }
 #pragma unroll
-            for (int j = 0; j < kPB; ++j) pin(prb[j]);
-#pragma unroll
-            for (int j = 0; j < kPB; ++j) {
-                const int i = i0 + j;
-                if (i >= N) break;
-                const int a = (int)(arow[i] * ms);
-                const float pr = prb[j];
-                if (calm && a > min_action && pr > 0.0f) {
-                    const double q = floordiv_true(amt, (double)pr);              // amount // price
-                    const double buy = ((double)a < q) ? (double)a : q;           // min(q, a)
-                    const float s = scol[i * kWave];
-                    scol[i * kWave] = (float)((double)s + buy);
-                    amt = amt - (((double)pr * buy) * one_p.v);
-                    ccol[i * kWave] = 0.0f;
-                }
-            }
+        for (int i = 0; i < kMaxN; ++i) {
+            if (i >= N) continue;
+            scol[i * kWave] = sr[i];
+            ccol[i * kWave] = cr[i];
         }
         amount = mk(amt, FINENV_NT_F64);
     } else {
@@ -495,7 +535,19 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
         }
     }
     NSTAMP(4);
-    np_write_rows(p.obs, p, e0, nenv_w, row_day, valid_mask, heads, lane, 0, kpatch);
+    head_park(ldshead, head_tt, lane);
+    lds_barrier();                           // hand-off: heads are final (pairs with the streamers')
+    if (!NDIAG(2)) {
+        HeadPlan<kHeadMax> hp;
+        head_plan(hp, ldshead, p.D, row_day, day0, valid_mask, lane, kpatch, head_widx);
+        if (done_mask == 0ull && hp.uniform)
+            head_store(hp, p.obs, p.D, e0, nenv_w, valid_mask, lane, 0, kWave / 2,
+                       [heads](int el, int w) { return heads[el * kRowH + w]; });
+        else
+            np_write_rows(p.obs, p, e0, nenv_w, row_day,
+                          done_mask != 0ull ? valid_mask : (valid_mask & 0x00000000FFFFFFFFull),
+                          heads, lane, 0, kpatch);
+    }
     NSTAMP(5);
     if (valid) store_state(amount, ta, gr, ita, r.tag, row_day);
     NSTAMP(6);
@@ -620,6 +672,10 @@ int finenv_stocknp_step(finenv_stocknp *h, const float *actions, float *obs, flo
     p.auto_reset = auto_reset;
 #ifdef FINENV_DIAG
     p.dbg = g_finenv_dbg;
+    {
+        const char *d = getenv("FINENV_DIAG");
+        p.diag = d ? atoi(d) : 0;
+    }
 #endif
     hipLaunchKernelGGL((stocknp_kernel<false>), np_grid(h->cfg.n_envs), dim3(kWave * kWaves * 2), 0,
                        (hipStream_t)stream, p);
