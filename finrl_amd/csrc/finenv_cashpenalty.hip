@@ -17,6 +17,10 @@
 #include "finenv_dev.h"
 #include "finenv_host.h"
 
+#ifdef FINENV_DIAG
+extern unsigned long long *g_finenv_dbg;         // finenv_stock.hip (diagnostic builds)
+#endif
+
 namespace {
 
 constexpr int kWave = 64;
@@ -24,7 +28,8 @@ constexpr int kMaxN = FINENV_CASHPENALTY_MAX_ASSETS;
 constexpr int kRow = kMaxN + 1;
 constexpr int kWaves = 2;
 constexpr int kB = 8;                        // assets per load batch
-constexpr int kLdsPerWave = kWave * kRow + kMaxN * kWave * 2;   // rows + f64 transactions [i][lane]
+constexpr int kClStride = kMaxN + 1;           // f64 close rows [env][33]: odd stride, conflict-free
+constexpr int kLdsPerWave = kWave * kRow + kClStride * kWave * 2 + 2;   // rows + f64 closes [el][i]
 
 struct CpParams {
     finenv_cashpenalty_config cfg;
@@ -42,7 +47,21 @@ struct CpParams {
     int32_t rs_hi;                  // random_start: draw in [0, rs_hi) on the device (0 = off)
     unsigned long long rs_seed;
     double *audit;                  // optional [E][FINENV_AUDIT_HEAD + N] per-step log row, or NULL
+    unsigned long long *dbg;        // FINENV_DIAG builds only: [wave][16] s_memrealtime stamps
 };
+
+#ifdef FINENV_DIAG
+#define KSTAMP(k)                                                                           \
+    do {                                                                                    \
+        if (p.dbg != nullptr && lane == 0) {                                                \
+            __builtin_amdgcn_sched_barrier(0);                                              \
+            p.dbg[(size_t)(e0 / kWave) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();      \
+            __builtin_amdgcn_sched_barrier(0);                                              \
+        }                                                                                   \
+    } while (0)
+#else
+#define KSTAMP(k) do { } while (0)
+#endif
 
 #define KF(fld) (*at(p.st.f64, (unsigned)(fld) * (unsigned)E + (unsigned)e))
 #define KI(fld) (*at(p.st.i32, (unsigned)(fld) * (unsigned)E + (unsigned)e))
@@ -132,8 +151,58 @@ __device__ __forceinline__ void cp_write_rows_full(float *__restrict__ dst, cons
     }
 }
 
+// The two halves of cp_write_rows_full, so that the 64 x NCH row loads can be issued at the START of
+// the step (right after the day counters arrive, together with the holdings / closes the trade
+// needs) and be in flight during the whole computation: at the end only stores remain.
+template <int NCH>
+__device__ __forceinline__ void cp_rows_fetch(float (&t)[(NCH > 0 ? NCH : 1) * kWave],
+                                              const CpParams &p, int row_day, int lane)
+{
+    const int N = p.cfg.n_assets, D = p.D, W = D - 1 - N;
+    if (W <= 0) {                         // no information columns: panel.info may be NULL
+#pragma unroll
+        for (int j = 0; j < NCH * kWave; ++j) t[j] = 0.0f;
+        return;
+    }
+#pragma unroll
+    for (int el = 0; el < kWave; ++el) {
+        const int de = __builtin_amdgcn_readlane(row_day, el);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int col = k * kWave + lane;
+            const bool ld = col < D && col > N;
+            t[el * NCH + k] = *at(p.panel.info, (unsigned)(ld ? de * W + col - 1 - N : 0));
+        }
+    }
+}
+
+template <int NCH>
+__device__ __forceinline__ void cp_rows_store(const float (&t)[(NCH > 0 ? NCH : 1) * kWave],
+                                              float *__restrict__ dst, const CpParams &p, int e0,
+                                              int nenv_w, unsigned long long lane_mask,
+                                              const float *rows, int lane)
+{
+    const int N = p.cfg.n_assets, D = p.D, W = D - 1 - N;
+    float *const base = dst + (size_t)e0 * D;
+#pragma unroll
+    for (int el = 0; el < kWave; ++el) {
+        if (el >= nenv_w || !((lane_mask >> el) & 1ull)) continue;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int col = k * kWave + lane;
+            float v = W > 0 ? t[el * NCH + k] : 0.0f;
+            if (k == 0) {                       // N <= 32: cash / holdings sit in chunk 0 only
+                const bool head = col <= N;
+                const float hv = rows[el * kRow + (head ? col : 0)];
+                v = head ? hv : v;
+            }
+            if (col < D) *at(base, (unsigned)(el * D + col)) = v;
+        }
+    }
+}
+
 template <bool RESET_ONLY, int NCH>
-__global__ void __launch_bounds__(kWave *kWaves) cashpenalty_kernel(const CpParams p)
+__global__ void __launch_bounds__(kWave *kWaves, 1) cashpenalty_kernel(const CpParams p)
 {
     __shared__ __attribute__((aligned(16))) float lds_all[kWaves * kLdsPerWave];
     const int lane = threadIdx.x & (kWave - 1);
@@ -170,67 +239,89 @@ __global__ void __launch_bounds__(kWave *kWaves) cashpenalty_kernel(const CpPara
         return;
     }
 
-    // ---- action tile -> LDS rows --------------------------------------------------------------
-    stage_action_tile(rows, kRow, p.actions + (size_t)e0 * N, nenv_w, N, p.magicN, lane);
+    KSTAMP(0);
+    // ---- round trip 1: per-env scalars (the action tile is issued behind them) ----------------
     int di = KI(FINENV_KI_DATE_INDEX);
     const int start = KI(FINENV_KI_START);
     double coh = KF(FINENV_KF_COH);
     double turb = c.use_turbulence ? KF(FINENV_KF_TURBULENCE) : 0.0;
     double sum_trades = KF(FINENV_KF_SUM_TRADES);
     double logged_total = KF(FINENV_KF_LOGGED_TOTAL), logged_cash = KF(FINENV_KF_LOGGED_CASH);
+    stage_action_tile(rows, kRow, p.actions + (size_t)e0 * N, nenv_w, N, p.magicN, lane);
     const int step = di - start;                                                 // current_step
     const bool at_end = di == c.n_days - 1;                                      // :299
     const unsigned cb = (unsigned)(di * N);
+    // ---- round trip 2, issued at once: holdings and closes of every asset, kept in registers (the
+    // first form fetched them in four dependent batches of 8 and read the holdings a second time
+    // for the book update: 12 us of a 28 us step) ---------------------------------------------------
+    double hb[kMaxN], clb[kMaxN];
+#pragma unroll
+    for (int i = 0; i < kMaxN; ++i) hb[i] = KH(min(i, N - 1));
+    // closes: every env sits on its own date (random starts), so a per-lane load touches 64
+    // different rows per instruction.  Row-wise instead: lane i < N loads close[date_el][i] for one
+    // env el per instruction (one 8N-byte segment), 16 rows in flight, parked in LDS [el][i]; each
+    // lane then reads its own row back.
+    {
+        const int li = min(lane, N - 1);
+        for (int g = 0; g < kWave; g += 16) {
+            double cv[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int de = __builtin_amdgcn_readlane(di, g + j);
+                cv[j] = *at(p.panel.close, (unsigned)(de * N + li));
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (lane < N) trl[(g + j) * kClStride + lane] = cv[j];
+        }
+    }
+    (void)cb;
     wave_sync();
+#pragma unroll
+    for (int i = 0; i < kMaxN; ++i) clb[i] = trl[lane * kClStride + min(i, N - 1)];
+    KSTAMP(1);
+    float act[kMaxN];
+#pragma unroll
+    for (int i = 0; i < kMaxN; ++i) act[i] = row[min(i, N - 1)];
 
     double reward;
     bool done = at_end;
     const float hmaxf = (float)c.hmax;
     const bool turbulent = c.use_turbulence && turb >= c.turbulence_threshold;
     double asset_value = 0.0, proceeds = 0.0, spend = 0.0;
-    for (int i = 0; i < N; ++i) sum_trades += fabs((double)row[i]);              // :293
+#pragma unroll
+    for (int i = 0; i < kMaxN; ++i)
+        if (i < N) sum_trades += fabs((double)act[i]);                           // :293
+    double tr_[kMaxN];
     if (!at_end) {
-        // batches of kB assets, the batch's global loads issued first (a rolled loop exposes one
-        // HBM round trip per asset at one wave per SIMD)
-        for (int i0 = 0; i0 < N; i0 += kB) {
-            double hb[kB], clb[kB];
 #pragma unroll
-            for (int j = 0; j < kB; ++j) {
-                const int i = min(i0 + j, N - 1);
-                hb[j] = KH(i);
-                clb[j] = *at(p.panel.close, cb + (unsigned)i);
+        for (int i = 0; i < kMaxN; ++i) {
+            if (i >= N) continue;              // (continue, not break: keeps the loop fully unrollable)
+            const double h = hb[i], cl = clb[i];
+            asset_value += h * cl;                                               // np.dot, :310
+            const float a32 = act[i] * hmaxf;                                    // :257 (float32)
+            const float a = cl > 0.0 ? a32 : 0.0f;                               // :260
+            double tr;
+            if (c.discrete_actions) {                                            // :263-274
+                // integer-valued doubles instead of int64 arithmetic (exact below 2^53; a software
+                // 64-bit division per asset, unrolled, was 30 KB of code)
+                const double q = cp_floordiv((double)a, cl);
+                const double inc = (double)c.shares_increment;
+                const double num = q >= 0.0 ? q : q + inc;
+                tr = cp_floordiv(num, inc) * inc;
+            } else {
+                tr = (double)a / cl;                                             // :276
             }
-#pragma unroll
-            for (int j = 0; j < kB; ++j) { pin(hb[j]); pin(clb[j]); }
-#pragma unroll
-            for (int j = 0; j < kB; ++j) {
-                const int i = i0 + j;
-                if (i >= N) continue;          // (continue, not break: keeps the loop fully unrollable)
-                const double h = hb[j], cl = clb[j];
-                asset_value += h * cl;                                           // np.dot, :310
-                const float a32 = row[i] * hmaxf;                                // :257 (float32)
-                const float a = cl > 0.0 ? a32 : 0.0f;                           // :260
-                double tr;
-                if (c.discrete_actions) {                                        // :263-274
-                    long long q = (long long)cp_floordiv((double)a, cl);
-                    const long long inc = c.shares_increment;
-                    const long long num = q >= 0 ? q : q + inc;
-                    long long fq = num / inc;
-                    if ((num % inc != 0) && ((num < 0) != (inc < 0))) fq -= 1;
-                    tr = (double)(fq * inc);
-                } else {
-                    tr = (double)a / cl;                                         // :276
-                }
-                tr = fmax(tr, -h);                                               // :279
-                tr = turbulent ? -h : tr;                                        // :282-287
-                trl[i * kWave + lane] = tr;
-                proceeds += (tr < 0.0 ? -tr : 0.0) * cl;                         // :323-324
-                spend += (tr > 0.0 ? tr : 0.0) * cl;                             // :328-329
-            }
+            tr = fmax(tr, -h);                                                   // :279
+            tr = turbulent ? -h : tr;                                            // :282-287
+            tr_[i] = tr;
+            proceeds += (tr < 0.0 ? -tr : 0.0) * cl;                             // :323-324
+            spend += (tr > 0.0 ? tr : 0.0) * cl;                                 // :328-329
         }
         logged_cash = coh;                                                       // :312-314
         logged_total = coh + asset_value;
     }
+    KSTAMP(2);
     reward = cp_reward(c, step, logged_total, logged_cash);                      // :317 / :301
     bool keep_buys = true;
     double coh_new = coh;
@@ -257,35 +348,43 @@ __global__ void __launch_bounds__(kWave *kWaves) cashpenalty_kernel(const CpPara
         au[FINENV_AUDIT_FLAGS] = (double)((at_end ? FINENV_AUDIT_F_LAST_DATE : 0) |
             ((!at_end && (done || !keep_buys)) ? FINENV_AUDIT_F_CASH_SHORTAGE : 0) |
             ((!at_end && turbulent) ? FINENV_AUDIT_F_TURBULENCE : 0));
-        for (int i = 0; i < N; ++i) {
-            const double tr = at_end ? 0.0 : trl[i * kWave + lane];
+#pragma unroll
+        for (int i = 0; i < kMaxN; ++i) {
+            if (i >= N) continue;
+            const double tr = at_end ? 0.0 : tr_[i];
             au[FINENV_AUDIT_HEAD + i] = (tr > 0.0 && !keep_buys) ? 0.0 : tr;     // :336 / :345
         }
     }
     const bool advance = !done;
+    // ---- the row of the panel each env's next observation shows is known from here on: date + 1,
+    // the unchanged date on a terminal step, or the new starting point on an auto-reset.  Its 64 x
+    // NCH market values are fetched NOW, before this wave's first store (a load issued behind
+    // stores waits for their acknowledgement), and fly during the book update / state stores ------
+    int ns_reset = 0;
+    if (p.auto_reset && __any(done))
+        ns_reset = p.rs_hi > 0 ? draw_start(p.rs_seed, e, KI(FINENV_KI_EPISODE) + 1, p.rs_hi)
+                               : KI(FINENV_KI_NEXT_START);
+    const int row_final = done ? (p.auto_reset ? ns_reset : di) : di + 1;
+    float trow[(NCH > 0 ? NCH : 1) * kWave];
+    if (NCH > 0) cp_rows_fetch<NCH>(trow, p, row_final, lane);
     if (advance) {
         coh = coh_new;
-        for (int i0 = 0; i0 < N; i0 += kB) {
-            double hb[kB];
 #pragma unroll
-            for (int j = 0; j < kB; ++j) hb[j] = KH(min(i0 + j, N - 1));
-#pragma unroll
-            for (int j = 0; j < kB; ++j) pin(hb[j]);
-#pragma unroll
-            for (int j = 0; j < kB; ++j) {
-                const int i = i0 + j;
-                if (i >= N) continue;          // (continue, not break: keeps the loop fully unrollable)
-                const double tr = trl[i * kWave + lane];
-                const double hn = hb[j] + ((tr > 0.0 && !keep_buys) ? 0.0 : tr); // :352
-                if (valid) KH(i) = hn;
-                row[1 + i] = (float)hn;
-            }
+        for (int i = 0; i < kMaxN; ++i) {
+            if (i >= N) continue;
+            const double tr = tr_[i];
+            const double hn = hb[i] + ((tr > 0.0 && !keep_buys) ? 0.0 : tr);     // :352
+            if (valid) KH(i) = hn;
+            row[1 + i] = (float)hn;
         }
         di += 1;                                                                 // :353
         if (c.use_turbulence) turb = *at(p.panel.turb, (unsigned)di);            // :354-357
     } else {
-        for (int i = 0; i < N; ++i) row[1 + i] = (float)KH(i);
+#pragma unroll
+        for (int i = 0; i < kMaxN; ++i)
+            if (i < N) row[1 + i] = (float)hb[i];
     }
+    KSTAMP(3);
     row[0] = (float)coh;
     if (valid) {
         *at(p.reward, (unsigned)e) = (float)reward;
@@ -304,8 +403,7 @@ __global__ void __launch_bounds__(kWave *kWaves) cashpenalty_kernel(const CpPara
         if (p.auto_reset) {                                                      // reset()
             wave_sync();
             if (done) {
-                const int ns = p.rs_hi > 0 ? draw_start(p.rs_seed, e, KI(FINENV_KI_EPISODE) + 1, p.rs_hi)
-                                           : KI(FINENV_KI_NEXT_START);
+                const int ns = ns_reset;
                 di = ns;
                 row_day = ns;
                 coh = c.initial_amount;
@@ -324,15 +422,13 @@ __global__ void __launch_bounds__(kWave *kWaves) cashpenalty_kernel(const CpPara
             wave_sync();
         }
     }
-    bool rows_done = false;
+    KSTAMP(4);
     if (NCH > 0) {
-        const int d0 = __builtin_amdgcn_readfirstlane(row_day);
-        if (!__all(row_day == d0)) {
-            cp_write_rows_full<NCH>(p.obs, p, e0, nenv_w, row_day, valid_mask, rows, lane);
-            rows_done = true;
-        }
+        cp_rows_store<NCH>(trow, p.obs, p, e0, nenv_w, valid_mask, rows, lane);   // (row_day == row_final)
+    } else {
+        cp_write_rows(p.obs, p, e0, nenv_w, row_day, valid_mask, rows, lane);
     }
-    if (!rows_done) cp_write_rows(p.obs, p, e0, nenv_w, row_day, valid_mask, rows, lane);
+    KSTAMP(5);
     if (valid) {
         KF(FINENV_KF_COH) = coh;
         KI(FINENV_KI_DATE_INDEX) = di;
@@ -484,6 +580,9 @@ int finenv_cashpenalty_step(finenv_cashpenalty *h, const float *actions, float *
     p.done = done;
     p.term_obs = term_obs;
     p.auto_reset = auto_reset;
+#ifdef FINENV_DIAG
+    p.dbg = g_finenv_dbg;
+#endif
     const dim3 grid = kp_grid(h->cfg.n_envs), block(kWave * kWaves);
     switch ((h->D + kWave - 1) / kWave) {      // chunks per observation row
     case 1: hipLaunchKernelGGL((cashpenalty_kernel<false, 1>), grid, block, 0, (hipStream_t)stream, p); break;

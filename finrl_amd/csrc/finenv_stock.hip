@@ -7,18 +7,20 @@
 // Python list + pandas object per env; here the state is a structure-of-arrays in HBM and
 // one wavefront lane owns one environment.
 //
-// Mapping (see DESIGN.md "stock_step"):
-//   * lane = env, wave = 64 envs, block = 4 independent waves (no block barriers);
+// Mapping (see DESIGN.md "stock_step"; kernels in finenv_stock_kernels.inc / finenv_stock_wide.inc,
+// compiled per padded ticker count in finenv_stock_np{32,64,128}.hip):
+//   * lane = env; one 128-thread block per 64 envs with TWO SPECIALISED WAVES: the "trader" owns
+//     the env state (staging, sort, sells, buys, assets, reward, state write-back), the "streamer"
+//     writes the market-data part of the observation rows from the first microsecond on; they meet
+//     at one hand-off barrier, after which both write the rows' cash / holdings chunk(s);
 //   * the wave's [64][N] action tile is read coalesced and transposed through LDS;
-//   * (action, ticker) pairs become 32 composite int keys per lane, sorted in VGPRs by a
-//     191-compare-exchange Batcher network == the reference's stable argsort order;
-//   * sells then buys walk the sorted keys; holdings live in LDS as [ticker][lane]
-//     (bank = lane, conflict-free under per-lane dynamic ticker index); the cash chain is
-//     fp64 with the reference's operation order (-ffp-contract=off), floor division is
-//     exact (reciprocal + FMA-remainder correction);
-//   * the [64][D] f32 observation block -- 76 % of all bytes -- is streamed out by the
-//     whole wave row by row from a pre-packed f32 panel row (L2-resident), patching in
-//     cash/holdings from LDS.
+//   * (action, ticker) pairs become composite int keys per lane, sorted in VGPRs by a Batcher
+//     network == the reference's stable argsort order;
+//   * sells then buys walk the sorted keys; holdings live in LDS as [ticker][lane]; the cash chain
+//     is fp64 with the reference's operation order (-ffp-contract=off), floor division is exact
+//     (reciprocal + FMA-remainder correction);
+//   * the [64][D] f32 observation block -- 76 % of all bytes -- comes from a pre-packed f32 panel
+//     row (L2-resident); cash / holdings are patched in from LDS.
 // HBM-bound by design (no MFMA: there is no contraction here).
 
 #include "finenv_stock_common.h"

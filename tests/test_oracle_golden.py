@@ -136,3 +136,30 @@ def test_unaffordable_buy_zero_fill():
     obs, rew, done = o.step(np.ones((1, fx.N), np.float32))
     st = o.state()
     assert (st["shares"] == 0).all() and st["cash"][0] == 50.0 and st["trades"][0] == fx.N
+
+
+@pytest.mark.parametrize("name", ["ties", "turbulence", "cashbound", "tiefree"])
+def test_pandas_shaped_env_matches_reference(name):
+    """oracle/pandas_env.py (the reference-SHAPED Python env timed as `cpu_baseline_python`) replays
+    the reference-recorded episodes exactly: float64 observations, rewards, cash, shares, cost,
+    trades, including the stale-row reset quirk."""
+    from oracle.pandas_env import PandasStockEnv, make_frame
+    fx = StockFixture(name)
+    z = fx.z
+    if not (fx.initial and fx.day0 == 0 and fx.reset_first):
+        pytest.skip("plain constructor path only")
+    env = PandasStockEnv(make_frame(fx.close, fx.tech, fx.risk), hmax=fx.hmax,
+                         initial_amount=fx.cash0, num_stock_shares=fx.shares0.tolist(),
+                         buy_cost_pct=fx.buy_cost_pct, sell_cost_pct=fx.sell_cost_pct,
+                         reward_scaling=fx.reward_scaling,
+                         turbulence_threshold=fx.turbulence_threshold)
+    resets = dict(zip(z["reset_step"].tolist(), z["reset_obs"]))
+    np.testing.assert_array_equal(np.asarray(env.reset(), np.float64), resets[-1])
+    for s in range(fx.S):
+        obs, rew, done, _ = env.step(fx.actions[s])
+        assert done == z["done"][s] and rew == z["reward"][s], s
+        assert env.cash == z["cash"][s] and env.cost == z["cost"][s] and env.trades == z["trades"][s]
+        np.testing.assert_array_equal(np.asarray(env.shares, np.float64), z["shares"][s])
+        np.testing.assert_array_equal(np.asarray(obs, np.float64), z["obs"][s])
+        if done:
+            np.testing.assert_array_equal(np.asarray(env.reset(), np.float64), resets[s])

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Per-phase timeline of the cash-penalty step kernel (diagnostic library only)."""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("FINENV_LIB", os.path.join(ROOT, "finrl_amd", "lib", "libfinenv_diag.so"))
+
+def main():
+    E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+    import torch
+    import bench
+    from finrl_amd import _native as nat
+    from finrl_amd.vec_cashpenalty import CashPenaltyPanel, VecCashPenaltyEnv
+    rng = np.random.default_rng(0)
+    T, N, Cc = bench.N_DAYS, bench.N_TICKERS, 5
+    close = 50 * np.exp(np.cumsum(rng.normal(0, 0.01, (T, N)), axis=0))
+    panel = CashPenaltyPanel(close, rng.normal(0, 10, (T, N, Cc)), np.abs(rng.normal(0, 30, T)))
+    env = VecCashPenaltyEnv(panel, E, hmax=2_000, random_start=True)
+    env.reset()
+    nw = (E + 63) // 64
+    buf = torch.zeros(nw * 16, dtype=torch.int64, device="cuda")
+    pool = [torch.rand(E, N, device="cuda") * 2 - 1 for _ in range(8)]
+    for i in range(300):
+        env.step(pool[i & 7])
+    L = nat.lib()
+    L.finenv_diag_set_stamp_buffer.argtypes = [C.c_void_p]
+    L.finenv_diag_set_stamp_buffer(C.c_void_p(buf.data_ptr()))
+    acc = []
+    for i in range(20):
+        buf.zero_()
+        env.step(pool[i & 7])
+        torch.cuda.synchronize()
+        acc.append(buf.cpu().numpy().reshape(nw, 16).astype(np.float64) * 0.01)
+    a = np.stack(acc)
+    rel = a - a[:, :, 0].min(axis=1)[:, None, None]
+    names = ["start", "tile + state staged", "transactions computed", "books updated",
+             "reward / state scalars stored", "obs rows written"]
+    print(f"cashpenalty E={E} waves={nw}; us since the first wave started (median; p95)")
+    for k, n in enumerate(names):
+        v = rel[:, :, k].reshape(-1)
+        print(f"  {k} {n:32s} {np.median(v):7.2f}  [{np.percentile(v, 95):7.2f}]")
+
+if __name__ == "__main__":
+    main()
