@@ -26,7 +26,7 @@ shows every rank taking part (`rccl` in the JSON).
 Other workloads (side metrics and BASELINE configs[2..4]): `--env portfolio|crypto|stocknp|
 cashpenalty|stoploss`, `--tickers 100 --turbulence-pct 90` (configs[3] per-GPU slice),
 `--env crypto --envs-per-gpu 32768 --rollout 16` (configs[4] per-GPU slice: steps write straight
-into [n_steps, E, .] rollout buffers, one GAE scan per segment).
+into [n_steps, E, .] rollout buffers, one GAE scan per segment, one hipGraph replay per segment).
 """
 from __future__ import annotations
 
@@ -368,18 +368,55 @@ def attach_rollout(w, args, torch, dev, gen):
     w.B_note += " + rollout: 8A + 8 + 17"
     state = dict(t=0)
 
-    def step(i):
-        t = state["t"]
+    def one(t, i):
         buf.actions[t].copy_(w.pool[i % len(w.pool)])
         buf.values[t].copy_(vals[i & 3])
         buf.log_probs[t].copy_(lps[i & 3])
         env.step(buf.actions[t], out=(buf.obs[t + 1], buf.rewards[t], buf.dones[t]))
-        t += 1
-        if t == n:
-            buf.compute_returns_and_advantage(vals[i & 3], gamma=0.99, gae_lambda=0.95)
-            buf.obs[0].copy_(buf.obs[n])
-            t = 0
-        state["t"] = t
+
+    def finish(i):
+        buf.compute_returns_and_advantage(vals[i & 3], gamma=0.99, gae_lambda=0.95)
+        buf.obs[0].copy_(buf.obs[n])
+
+    if args.no_graph:
+        def step(i):
+            t = state["t"]
+            one(t, i)
+            t += 1
+            if t == n:
+                finish(i)
+                t = 0
+            state["t"] = t
+        w.config_extra["launch"] = "eager (4 launches per step)"
+    else:
+        # a whole segment -- n x (3 buffer copies + env step) + GAE scan + carry-over copy -- is ONE
+        # hipGraph: replayed with one host call per n steps (every step() of the envs is a plain
+        # launch on the caller's stream: no allocation, sync or host read-back in the C ABI)
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                for t in range(n):
+                    one(t, t)
+                finish(n - 1)
+        cur.wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for t in range(n):
+                one(t, t)
+            finish(n - 1)
+        w.graph = graph
+
+        def step(i):
+            state["t"] += 1
+            if state["t"] == n:
+                graph.replay()
+                state["t"] = 0
+        for name in ("steps", "warmup"):
+            if getattr(args, name) % n:
+                raise SystemExit(f"--rollout {n} with graph replay needs --{name} to be a multiple of {n}")
+        w.config_extra["launch"] = f"hipGraph, one replay per {n}-step segment"
 
     def reset():
         buf.obs[0].copy_(env.reset())
@@ -424,6 +461,8 @@ def timed_region(work, steps, warmup, prewarm, world, dist, sync, make_events, g
             work.after_reset()
         state["in_ep"] = 0
     run(warmup, False)
+    if world > 1:                         # untimed: RCCL sets up its channels at the first call
+        gather_episode_returns(work.episode_return(), global_envs)
     ev0, ev1 = make_events()
     if world > 1:
         dist.barrier()
@@ -465,6 +504,9 @@ def main():
                     help="30 = DOW30 (headline); 100 = NASDAQ-100 shape (BASELINE configs[3])")
     ap.add_argument("--turbulence-pct", type=float, default=None,
                     help="turbulence_threshold = this percentile of the synthetic risk series")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="rollout mode: launch every copy / step eagerly instead of one hipGraph "
+                         "replay per segment")
     ap.add_argument("--rollout", type=int, default=0,
                     help="collect into [n_steps, E, .] rollout buffers + GAE scan per segment "
                          "(BASELINE configs[4])")

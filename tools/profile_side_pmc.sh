@@ -3,19 +3,19 @@
 # separate passes (MI355X_MICROARCH.md, HBM section), one pair per env.
 # Usage: bash tools/profile_side_pmc.sh <tag>  -> gpurun_out/prof_side_pmc_<tag>/<env>_traffic.json
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/prof_side_pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for ENV in portfolio crypto stocknp cashpenalty stoploss; do
   for CTR in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $CTR --output-format csv -d $OUT/${ENV}_$CTR -- python3 $ROOT/bench.py --env $ENV --steps 300 --warmup 50 > $OUT/${ENV}_$CTR.log 2>&1
+    rocprofv3 --pmc $CTR --output-format csv -d $OUT/${ENV}_$CTR -- python3 $ROOT/bench.py --env $ENV --steps 300 --warmup 50 --prewarm 0 --no-cpu-baseline > $OUT/${ENV}_$CTR.log 2>&1
   done
   python3 - "$OUT" "$ENV" <<'PY'
 import csv, glob, json, os, sys
 out, env = sys.argv[1], sys.argv[2]
-needle = {"portfolio": "portfolio_step_kernel", "crypto": "crypto_kernel<false>", "stocknp": "stocknp_kernel<false>",
+needle = {"portfolio": "portfolio_step_kernel", "crypto": "crypto_kernel<false", "stocknp": "stocknp_kernel<false>",
           "cashpenalty": "cashpenalty_kernel<false", "stoploss": "stoploss_kernel<false"}[env]
 def med(ctr):
     f = glob.glob(os.path.join(out, f"{env}_{ctr}", "**", "*counter_collection.csv"), recursive=True)

@@ -13,6 +13,7 @@ run portfolio --env portfolio --steps 1500 --warmup 300
 run crypto --env crypto --steps 3000 --warmup 500
 run crypto32k --env crypto --envs-per-gpu 32768 --steps 3000 --warmup 500
 run crypto32k_rollout --env crypto --envs-per-gpu 32768 --rollout 16 --steps 3200 --warmup 480
+run crypto32k_rollout_eager --env crypto --envs-per-gpu 32768 --rollout 16 --no-graph --steps 3200 --warmup 480
 run stocknp --env stocknp --steps 2000 --warmup 500
 run cashpenalty --env cashpenalty --steps 2000 --warmup 500
 run stoploss --env stoploss --steps 1500 --warmup 300

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Round-2 evidence on ONE box: rocprofv3 kernel stats + PMC traffic for every step kernel, then
+# the un-profiled bench lines.  Outputs under gpurun_out/ (copied into profiles/ afterwards).
+set -e
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+mkdir -p $ROOT/gpurun_out/r02
+bash tools/profile_stock.sh r02f_n30 > /dev/null 2>&1
+bash tools/profile_stock.sh r02f_n100 --tickers 100 --turbulence-pct 90 > /dev/null 2>&1
+bash tools/profile_stock.sh r02f_desync --desync > /dev/null 2>&1
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/r02/driver_trace_f -- python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $ROOT/gpurun_out/r02/driver_trace_f.log 2>&1 )
+bash tools/profile_side.sh r02f > /dev/null 2>&1
+bash tools/profile_side_pmc.sh r02f > /dev/null 2>&1
+bash tools/r02_bench_all.sh f
