@@ -140,7 +140,7 @@ __device__ __forceinline__ void sl_write_rows_full(float *__restrict__ dst, cons
 }
 
 template <bool RESET_ONLY, int NCH>
-__global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams p)
+__global__ void __launch_bounds__(kWave *kWaves, 1) stoploss_kernel(const SlParams p)
 {
     __shared__ __attribute__((aligned(16))) float lds_all[kWaves * kLdsPerWave];
     const int lane = threadIdx.x & (kWave - 1);
@@ -235,8 +235,14 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
     double coh_new = coh;
     const double coh_begin = coh;
     int audit_flags = at_end ? FINENV_AUDIT_F_LAST_DATE : 0;
+    // holdings, closes, average buy prices and transactions stay in statically indexed registers
+    // from pass 2 to pass 3 (the batch loops are unrolled over the kMaxN slots): pass 3 used to
+    // re-read the first three (1.22x the algorithmic traffic, profiles/side_traffic.json)
+    double hS[kMaxN], clS[kMaxN], abS[kMaxN], trS[kMaxN];
     if (!at_end) {
-        for (int i0 = 0; i0 < N; i0 += kB) {
+#pragma unroll
+        for (int i0 = 0; i0 < kMaxN; i0 += kB) {
+            if (i0 >= N) continue;
             double hb[kB], clb[kB], ab[kB], pb[kB], pso[kB], cdo[kB];
 #pragma unroll
             for (int j = 0; j < kB; ++j) {
@@ -267,12 +273,12 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
                 a = turbulent ? -(h * cl) : a;                                   // :327-331
                 double tr;
                 if (c.discrete_actions) {                                        // :333-343
-                    long long q = cl > 0.0 ? (long long)sl_floordiv(a, cl) : 0ll;
-                    const long long inc = c.shares_increment;
-                    const long long num = q >= 0 ? q : q + inc;
-                    long long fq = num / inc;
-                    if ((num % inc != 0) && ((num < 0) != (inc < 0))) fq -= 1;
-                    tr = (double)(fq * inc);
+                    // integer-valued doubles instead of int64 arithmetic (exact below 2^53; a
+                    // software 64-bit division per asset, unrolled, doubled the kernel's code)
+                    const double q = cl > 0.0 ? sl_floordiv(a, cl) : 0.0;
+                    const double inc = (double)c.shares_increment;
+                    const double num = q >= 0.0 ? q : q + inc;
+                    tr = sl_floordiv(num, inc) * inc;
                 } else {
                     tr = cl > 0.0 ? a / cl : 0.0;                                // :345
                 }
@@ -282,7 +288,10 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
                 slp_new += pb[j] * fmin(cd, 0.0);
                 tr = (stop_armed && cd < 0.0) ? -h : tr;                         // :353-357
                 audit_flags |= (stop_armed && cd < 0.0) ? FINENV_AUDIT_F_STOP_LOSS : 0;   // :359-360
-                trl[i * kWave + lane] = tr;
+                hS[i] = h;
+                clS[i] = cl;
+                abS[i] = abp;
+                trS[i] = tr;
                 proceeds += (tr < 0.0 ? -tr : 0.0) * cl;                         // :363-364
                 spend += (tr > 0.0 ? tr : 0.0) * cl;                             // :368-369
             }
@@ -313,25 +322,21 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
     if (advance) {
         coh = coh_new;
         double ntr = 0.0;
-        for (int i0 = 0; i0 < N; i0 += kB) {
-            double hb[kB], clb[kB], ab[kB], nbb[kB];
+        // buy counts: the one book pass 2 did not read -- all of them in one batch, before this
+        // pass's first store
+        double nbS[kMaxN];
 #pragma unroll
-            for (int j = 0; j < kB; ++j) {
-                const int i = min(i0 + j, N - 1);
-                clb[j] = *at(p.panel.close, cb + (unsigned)i);
-                hb[j] = LV(FINENV_LV_HOLDINGS, i);
-                ab[j] = LV(FINENV_LV_AVG_BUY_PRICE, i);
-                nbb[j] = LV(FINENV_LV_N_BUYS, i);
-            }
+        for (int i = 0; i < kMaxN; ++i) nbS[i] = LV(FINENV_LV_N_BUYS, min(i, N - 1));
 #pragma unroll
-            for (int j = 0; j < kB; ++j) { pin(hb[j]); pin(clb[j]); pin(ab[j]); pin(nbb[j]); }
+        for (int i0 = 0; i0 < kMaxN; i0 += kB) {
+            if (i0 >= N) continue;
 #pragma unroll
             for (int j = 0; j < kB; ++j) {
                 const int i = i0 + j;
                 if (i >= N) continue;          // (continue, not break: keeps the loop fully unrollable)
-                const double tr0 = trl[i * kWave + lane];
-                const double cl = clb[j], h = hb[j];
-                double abp = ab[j], nb = nbb[j];
+                const double tr0 = trS[i];
+                const double cl = clS[i], h = hS[i];
+                double abp = abS[i], nb = nbS[i];
                 const bool sold = tr0 < 0.0;                                     // sells > 0
                 const bool bought = tr0 > 0.0;                                   // buys > 0 (:418)
                 const double tr = (bought && !keep_buys) ? 0.0 : tr0;            // :376
@@ -370,8 +375,10 @@ __global__ void __launch_bounds__(kWave *kWaves) stoploss_kernel(const SlParams 
         au[FINENV_AUDIT_ASSET_VALUE] = asset_value;                              // :311
         au[FINENV_AUDIT_REWARD] = reward;
         au[FINENV_AUDIT_FLAGS] = (double)audit_flags;
-        for (int i = 0; i < N; ++i) {
-            const double tr = at_end ? 0.0 : trl[i * kWave + lane];
+#pragma unroll
+        for (int i = 0; i < kMaxN; ++i) {
+            if (i >= N) continue;
+            const double tr = at_end ? 0.0 : trS[i];
             au[FINENV_AUDIT_HEAD + i] = (tr > 0.0 && !keep_buys) ? 0.0 : tr;     // :376 / :385
         }
     }
