@@ -82,6 +82,67 @@ __global__ void __launch_bounds__(kThreads) rolling_risk_kernel(const RiskParams
     if (!QUAD) return;
     __syncthreads();
 
+    // ---- fast path: Cholesky.  With a well-conditioned covariance (every pivot above 1e-6 of the
+    // largest diagonal entry: condition number <~ 1e6, relative error of the quadratic form
+    // <~ 1e-10) pinv(C) IS the inverse and x' C^-1 x = |L^-1 x|^2 with C = L L'.  N^3/3 flops
+    // instead of the ~40 N^3 of the Jacobi sweeps below (148 ms -> a few ms at N = 100 over 2,893
+    // days); anything ill-conditioned (e.g. a duplicated ticker: rank deficient, where pinv drops
+    // the null space) falls through to the Jacobi diagonalisation, which applies NumPy's cutoff.
+    // The factor is built in a COPY below the diagonal bookkeeping: A's upper triangle (incl. the
+    // diagonal, saved in mean[]) stays intact for the fallback.
+    {
+        double dmax = 0.0;
+        for (int k = 0; k < N; ++k) dmax = fmax(dmax, A[k * S + k]);
+        const double tol = 1e-6 * dmax;
+        if (tid == 0) *flag = 0;
+        for (int j = tid; j < N; j += kThreads) mean[j] = A[j * S + j];     // keep the diagonal
+        __syncthreads();
+        bool ill = !(dmax > 0.0);
+        for (int k = 0; k < N && !ill; ++k) {
+            // (every thread reads the pivot after the previous step's barrier)
+            const double dk = A[k * S + k];
+            if (!(dk > tol)) { ill = true; break; }                          // uniform: same dk
+            const double lkk = sqrt(dk);
+            __syncthreads();                                                 // all have read dk
+            for (int i = k + 1 + tid; i < N; i += kThreads) A[i * S + k] /= lkk;   // column k of L
+            if (tid == 0) {
+                A[k * S + k] = lkk;
+                x[k] = x[k] / lkk;                                           // forward solve: y_k
+            }
+            __syncthreads();
+            // trailing update of the lower triangle and of the right-hand side
+            const double yk = x[k];
+            for (int i = k + 1 + (tid >> 4); i < N; i += kThreads >> 4) {
+                const double lik = A[i * S + k];
+                for (int j = k + 1 + (tid & 15); j <= i; j += 16) A[i * S + j] -= lik * A[j * S + k];
+                if ((tid & 15) == 0) x[i] -= lik * yk;
+            }
+            __syncthreads();
+        }
+        if (!ill) {
+            if (tid == 0) {
+                double q = 0.0;
+                for (int k = 0; k < N; ++k) q += x[k] * x[k];
+                p.quad_out[d] = q;                                           // temp, :244-246
+            }
+            return;
+        }
+        // fallback: restore the symmetric matrix (lower triangle + diagonal from the intact upper
+        // triangle / saved diagonal) and the de-meaned return, then diagonalise
+        __syncthreads();
+        for (int f = tid; f < N * N; f += kThreads) {
+            const int a = f / N, b = f - a * N;
+            if (b < a) A[a * S + b] = A[b * S + a];
+            else if (a == b) A[a * S + a] = mean[a];
+        }
+        for (int j = tid; j < N; j += kThreads) {
+            double s = 0.0;
+            for (int t = lo; t < hi; ++t) s += p.ret[(size_t)t * N + j];
+            x[j] = p.ret[(size_t)d * N + j] - s / (double)n;
+        }
+        __syncthreads();
+    }
+
     double tr0 = 0.0;
     for (int k = 0; k < N; ++k) tr0 += fabs(A[k * S + k]);
     const double floor_abs = 1e-26 * tr0;
