@@ -49,7 +49,7 @@ class StockPanelPtrs(C.Structure):
 
 # Field order of the two [field][E] state blocks (include/finenv.h enums)
 STOCK_F64_FIELDS = ("cash", "cost", "last_reward", "turbulence", "asset0", "ret_sum", "ret_sumsq",
-                    "cash0")
+                    "cash0", "begin_asset")
 STOCK_I32_FIELDS = ("day", "price_day", "trades", "episode", "start_day")
 
 

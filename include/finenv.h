@@ -105,6 +105,12 @@ enum {                            /* f64 block: double f64[FINENV_STOCK_F64_FIEL
     FINENV_SF_RET_SUM,            /* sum of pct_change(asset_memory) this episode        */
     FINENV_SF_RET_SUMSQ,          /* sum of its squares (Sharpe at the terminal step)    */
     FINENV_SF_CASH0,              /* initial_amount / previous_state[0] (read-only)      */
+    FINENV_SF_BEGIN_ASSET,        /* cash + sum(close * shares) of the CURRENT observation,
+                                     summed sequentially from ticker 0 as :311-314 does: the
+                                     next step's begin_total_asset.  It is the previous step's
+                                     end_total_asset bit for bit (same state list, same
+                                     expression, :344-347), so step() carries it over instead
+                                     of recomputing it; init / reset evaluate it afresh       */
     FINENV_STOCK_F64_FIELDS
 };
 enum {                            /* i32 block: int32 i32[FINENV_STOCK_I32_FIELDS+2N][E] */

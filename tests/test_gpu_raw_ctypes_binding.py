@@ -43,7 +43,7 @@ def test_documented_ctypes_stub_runs_and_matches():
     E, N, K, T = 200, 30, 8, 50
     D = 1 + 2 * N + K * N
     dev = "cuda"
-    f64 = torch.zeros(8, E, dtype=torch.float64, device=dev)          # FINENV_SF_* rows
+    f64 = torch.zeros(9, E, dtype=torch.float64, device=dev)          # FINENV_SF_* rows
     i32 = torch.zeros(5 + 2 * N, E, dtype=torch.int32, device=dev)    # FINENV_SI_* rows, holdings, shares0
     f64[7] = 1_000_000.0                                              # FINENV_SF_CASH0
     close_t = torch.from_numpy(panel.signed_close()).to(dev)          # sign bit = untradable flag
