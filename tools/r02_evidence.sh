@@ -11,3 +11,12 @@ bash tools/profile_stock.sh r02f_desync --desync > /dev/null 2>&1
 bash tools/profile_side.sh r02f > /dev/null 2>&1
 bash tools/profile_side_pmc.sh r02f > /dev/null 2>&1
 bash tools/r02_bench_all.sh f
+python3 tools/bench_riskpre.py 2>/dev/null | grep shape > $ROOT/gpurun_out/r02/f_riskpre.jsonl
+python3 tools/phase_times.py 65536 30 2>&1 | grep -v amdgpu.ids > $ROOT/gpurun_out/r02/f_phase_n30.txt
+python3 tools/phase_times.py 65536 100 2>&1 | grep -v amdgpu.ids > $ROOT/gpurun_out/r02/f_phase_n100.txt
+python3 tools/phase_times_crypto.py 32768 2>&1 | grep -v amdgpu.ids > $ROOT/gpurun_out/r02/f_phase_crypto.txt
+python3 tools/phase_times_stocknp.py 2>&1 | grep -v amdgpu.ids > $ROOT/gpurun_out/r02/f_phase_stocknp.txt
+python3 tools/phase_times_cashpenalty.py 2>&1 | grep -v amdgpu.ids > $ROOT/gpurun_out/r02/f_phase_cashpenalty.txt
+python3 -c "import __graft_entry__ as g; g.smoke()" > $ROOT/gpurun_out/r02/f_smoke.txt 2>&1
+python3 bench.py > $ROOT/gpurun_out/r02/f_default_bench.json 2> $ROOT/gpurun_out/r02/f_default_bench.err
+tail -c 600 $ROOT/gpurun_out/r02/f_default_bench.json
