@@ -20,8 +20,9 @@ the prewarm vs 20.9 in a 8,679-step run).
 
 N > 1: independent env shards per rank (weak scaling), no data-path collective; the only
 collective is the RCCL all_gather of per-env episode returns at each episode end,
-inside the timed region -- and at least once per timed region, so that a short scaling run still
-shows every rank taking part (`rccl` in the JSON).
+inside the timed region -- and at least once per timed region (half way through and asynchronous
+when no episode ends in it), so that a short scaling run still shows every rank taking part
+(`rccl` in the JSON).
 
 Other workloads (side metrics and BASELINE configs[2..4]): `--env portfolio|crypto|stocknp|
 cashpenalty|stoploss`, `--tickers 100 --turbulence-pct 90` (configs[3] per-GPU slice),
@@ -429,21 +430,34 @@ def attach_rollout(w, args, torch, dev, gen):
 def timed_region(work, steps, warmup, prewarm, world, dist, sync, make_events, global_envs=None):
     """prewarm (untimed, then reset) -> warmup (untimed) -> EXACTLY `steps` steps between barrier +
     synchronize pairs.  Episode ends inside the timed region gather the per-env episode returns
-    over all ranks; when no episode ends there (short runs) ONE gather runs at the end of the
-    region, so every multi-rank run exercises the collective.  Returns wall seconds (max over
+    over all ranks; when no episode ends there (short runs) ONE asynchronous gather runs half way
+    through and is waited for before the region closes, so every multi-rank run exercises the
+    collective.  Returns wall seconds (max over
     ranks is taken by the caller), device milliseconds and the rccl record."""
     from finrl_amd.distributed import gather_episode_returns
     state = dict(in_ep=0, gathers=0, gathered=0)
     L = work.episode_len
 
-    def gather():
-        out = gather_episode_returns(work.episode_return(), global_envs)
+    pending = []
+
+    def gather(async_op=False):
+        out = gather_episode_returns(work.episode_return(), global_envs, async_op=async_op)
         state["gathers"] += 1
-        state["gathered"] = int(out.numel())
+        if async_op:
+            pending.append(out)
+        else:
+            state["gathered"] = int(out.numel())
 
     def run(n, timed):
+        # a timed region too short to contain an episode end gathers ONCE, half way through and
+        # asynchronously: the collective runs on RCCL's stream beside the following steps and is
+        # waited for before the region closes (at its end it would sit fully exposed on a 20-step
+        # region: ~100 us of host + device time against 420 us of steps)
+        forced_at = n // 2 if (timed and world > 1 and (L is None or state["in_ep"] + n < L)) else -1
         for i in range(n):
             work.step(i)
+            if i == forced_at:
+                gather(async_op=True)
             if L is not None:
                 state["in_ep"] += 1
                 if state["in_ep"] == L:
@@ -470,8 +484,8 @@ def timed_region(work, steps, warmup, prewarm, world, dist, sync, make_events, g
     t0 = time.perf_counter()
     ev0.record()
     run(steps, True)
-    if world > 1 and state["gathers"] == 0:
-        gather()
+    for h in pending:
+        state["gathered"] = int(h.wait().numel())
     ev1.record()
     sync()
     if world > 1:

@@ -77,8 +77,25 @@ def make_sharded_env(panel, global_envs: int, *, kind="stock", rank=None, world=
     return env_class(kind)(panel, n_local, device=device, **kw)
 
 
-def gather_episode_returns(local_returns, global_envs: int = None, group=None):
+class _PendingGather:
+    """Handle of an asynchronous gather: ``wait()`` blocks the current stream on the collective and
+    returns the gathered tensor."""
+
+    def __init__(self, out, work, finish=None):
+        self._out, self._work, self._finish = out, work, finish
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return self._finish(self._out) if self._finish is not None else self._out
+
+
+def gather_episode_returns(local_returns, global_envs: int = None, group=None, async_op=False):
     """All-gather the per-env episode returns of every rank into global env order.
+
+    async_op=True: the collective is only enqueued (on RCCL's own stream) and a handle is returned;
+    env steps launched meanwhile overlap with it, ``handle.wait()`` yields the gathered tensor.
 
     local_returns: 1-D tensor (this rank's envs, in local order).  Returns a 1-D tensor of
     length sum(shard sizes) on the same device, identical on every rank.  Which collective runs
@@ -91,22 +108,27 @@ def gather_episode_returns(local_returns, global_envs: int = None, group=None):
     import torch
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return local_returns.clone()
+        out = local_returns.clone()
+        return _PendingGather(out, None) if async_op else out
     world = dist.get_world_size(group)
     n = local_returns.numel()
     if global_envs is None or global_envs % world == 0:
         if global_envs is not None and n * world != global_envs:
             raise ValueError(f"rank holds {n} envs, expected {global_envs // world}")
         out = torch.empty(n * world, dtype=local_returns.dtype, device=local_returns.device)
-        dist.all_gather_into_tensor(out, local_returns.contiguous(), group=group)
-        return out
+        work = dist.all_gather_into_tensor(out, local_returns.contiguous(), group=group,
+                                           async_op=async_op)
+        return _PendingGather(out, work) if async_op else out
     sizes = [shard_range(global_envs, r, world) for r in range(world)]
     nmax = max(hi - lo for lo, hi in sizes)
     pad = torch.zeros(nmax, dtype=local_returns.dtype, device=local_returns.device)
     pad[:n] = local_returns
     parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad, group=group)
-    return torch.cat([p[:hi - lo] for p, (lo, hi) in zip(parts, sizes)])
+    work = dist.all_gather(parts, pad, group=group, async_op=async_op)
+
+    def finish(ps):
+        return torch.cat([p[:hi - lo] for p, (lo, hi) in zip(ps, sizes)])
+    return _PendingGather(parts, work, finish) if async_op else finish(parts)
 
 
 def reduce_return_stats(local_returns, group=None):
