@@ -98,7 +98,7 @@ class StockNpConfig(C.Structure):
                 ("n_days", C.c_int32), ("min_action", C.c_int32), ("reserved0", C.c_int32),
                 ("max_stock", C.c_double), ("buy_cost_pct", C.c_double),
                 ("sell_cost_pct", C.c_double), ("reward_scaling", C.c_double),
-                ("gamma", C.c_double)]
+                ("gamma", C.c_double), ("obs_amount_floor", C.c_double)]
 
 
 class StockNpPanelPtrs(C.Structure):

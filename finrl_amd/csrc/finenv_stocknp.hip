@@ -224,7 +224,11 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
         gr = mk(0.0, FINENV_NT_PY);
     };
     auto fill_head = [&](Num amount) {
-        head[0] = (float)n_mul(amount, mk(0x1p-12, FINENV_NT_PY)).v;             // :150
+        // env_nas100_wrds.py:154: Python's max(self.amount, 1e4) keeps self.amount (and its NumPy
+        // scalar type) unless the floor is strictly larger, then it is the Python float
+        const double fl = p.cfg.obs_amount_floor;
+        const Num shown = (fl > 0.0 && fl > amount.v) ? mk(fl, FINENV_NT_PY) : amount;
+        head[0] = (float)n_mul(shown, mk(0x1p-12, FINENV_NT_PY)).v;              // :150
         for (int i = 0; i < N; ++i) {
             head[1 + i] = scol[i * kWave] * 0x1p-6f;
             head[1 + N + i] = ccol[i * kWave];

@@ -38,7 +38,7 @@ class VecStockTradingEnvNP:
     def __init__(self, config, num_envs, *, gamma=0.99, turbulence_thresh=99, min_stock_rate=0.1,
                  max_stock=1e2, initial_capital=1e6, buy_cost_pct=1e-3, sell_cost_pct=1e-3,
                  reward_scaling=2 ** -11, initial_stocks=None, auto_reset=True, device="cuda",
-                 seed=0):
+                 seed=0, obs_amount_floor=0.0):
         import torch
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -67,7 +67,7 @@ class VecStockTradingEnvNP:
         L = nat.lib()
         self._cfg = nat.StockNpConfig(E, N, W, T, int(max_stock * min_stock_rate), 0,
                                       float(max_stock), float(buy_cost_pct), float(sell_cost_pct),
-                                      float(reward_scaling), float(gamma))
+                                      float(reward_scaling), float(gamma), float(obs_amount_floor))
         self._h = C.c_void_p()
         nat.check(L.finenv_stocknp_create(C.byref(self._cfg), C.byref(self._h)), None,
                   "finenv_stocknp_create")

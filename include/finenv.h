@@ -328,6 +328,9 @@ typedef struct finenv_stocknp_config {
     int32_t reserved0;
     double  max_stock;            /* :39 (action scale, :104)                             */
     double  buy_cost_pct, sell_cost_pct, reward_scaling, gamma;
+    double  obs_amount_floor;     /* 0: the observation shows self.amount (:150); > 0: Python's
+                                     max(self.amount, floor) as StockEnvNAS100.get_state does
+                                     (env_nas100_wrds.py:154, floor = 1e4)                 */
 } finenv_stocknp_config;
 
 typedef struct finenv_stocknp_panel {

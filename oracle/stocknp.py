@@ -16,7 +16,8 @@ class NpCfg(C.Structure):
                 ("n_days", C.c_int32), ("max_stock_i", C.c_int32), ("min_action", C.c_int32),
                 ("max_stock", C.c_double), ("buy_cost_pct", C.c_double),
                 ("sell_cost_pct", C.c_double), ("reward_scaling", C.c_double),
-                ("gamma", C.c_double), ("initial_capital", C.c_double)]
+                ("gamma", C.c_double), ("initial_capital", C.c_double),
+                ("obs_amount_floor", C.c_double)]
 
 
 def derive_arrays(price_array, tech_array, turbulence_array, turbulence_thresh=99):
@@ -39,7 +40,8 @@ def derive_arrays(price_array, tech_array, turbulence_array, turbulence_thresh=9
 class StockNpOracle:
     def __init__(self, price_array, tech_array, turbulence_array, *, n_envs=1, gamma=0.99,
                  turbulence_thresh=99, min_stock_rate=0.1, max_stock=1e2, initial_capital=1e6,
-                 buy_cost_pct=1e-3, sell_cost_pct=1e-3, reward_scaling=2 ** -11):
+                 buy_cost_pct=1e-3, sell_cost_pct=1e-3, reward_scaling=2 ** -11,
+                 obs_amount_floor=0.0):
         self.price, self.tech, self.turb, self.turb_bool = derive_arrays(
             price_array, tech_array, turbulence_array, turbulence_thresh)
         T, N = self.price.shape
@@ -50,7 +52,8 @@ class StockNpOracle:
         L.np_oracle_create.restype = C.c_void_p
         self.cfg = NpCfg(self.E, N, self.W, T, int(max_stock), int(max_stock * min_stock_rate),
                          float(max_stock), float(buy_cost_pct), float(sell_cost_pct),
-                         float(reward_scaling), float(gamma), float(initial_capital))
+                         float(reward_scaling), float(gamma), float(initial_capital),
+                         float(obs_amount_floor))
         self._h = C.c_void_p(L.np_oracle_create(C.byref(self.cfg), _p(self.price), _p(self.tech),
                                                 _p(self.turb), _p(self.turb_bool)))
 

@@ -30,6 +30,8 @@ typedef struct {
     int32_t min_action;         /* int(max_stock * min_stock_rate), :111                   */
     double max_stock;           /* :39                                                     */
     double buy_cost_pct, sell_cost_pct, reward_scaling, gamma, initial_capital;
+    double obs_amount_floor;    /* 0: get_state shows self.amount (env_stocktrading_np.py:150);
+                                   1e4: max(self.amount, 1e4), env_nas100_wrds.py:154          */
 } np_cfg;
 
 typedef struct {
@@ -175,7 +177,11 @@ static void write_obs(const np_oracle *o, int e, const float *price, float *obs)
 {
     const int N = o->cfg.n_tickers, W = o->cfg.n_techw, d = o->day[e];
     const float *st = o->stocks + (size_t)e * N, *cd = o->cool_down + (size_t)e * N;
-    const num a = n_mul(o->amount[e], mk(0x1p-12, TAG_PY));        /* self.amount * 2**-12 */
+    /* env_nas100_wrds.py:154: Python's max(self.amount, 1e4) returns self.amount (with its NumPy
+     * scalar type) unless 1e4 is strictly larger, in which case the Python float 1e4 */
+    const num shown = (o->cfg.obs_amount_floor > 0.0 && o->cfg.obs_amount_floor > o->amount[e].v)
+                          ? mk(o->cfg.obs_amount_floor, TAG_PY) : o->amount[e];
+    const num a = n_mul(shown, mk(0x1p-12, TAG_PY));               /* ... * 2**-12 */
     obs[0] = (float)a.v;
     obs[1] = o->turb[d];
     obs[2] = o->turb_bool[d];

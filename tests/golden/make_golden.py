@@ -378,18 +378,40 @@ def _tag(x):
 
 
 def run_stocknp(name, *, seed, T, N, K, S, if_train=False, initial_capital=1e6, max_stock=1e2,
-                turb_scale=60.0, buy_cost_pct=1e-3, sell_cost_pct=1e-3, gamma=0.99):
+                turb_scale=60.0, buy_cost_pct=1e-3, sell_cost_pct=1e-3, gamma=0.99, nas100=False,
+                data_gap=1, turbulence_thresh=99):
     """Unmodified reference env_stocktrading_np.StockTradingEnv (NumPy-version dependent mixed
-    float32/float64 arithmetic: the dtype of every scalar is recorded next to its value)."""
-    mod = rh.load_stocktrading_np()
+    float32/float64 arithmetic: the dtype of every scalar is recorded next to its value).
+    nas100=True: env_nas100_wrds.StockEnvNAS100 instead -- the same step on float32 arrays handed
+    over directly (cwd=None, if_eval=True: rows [0:211210:data_gap]), a random start state at
+    every reset and an observation that shows max(amount, 1e4)."""
     rng = np.random.default_rng(seed + 4000)
-    price = 100 * np.exp(np.cumsum(rng.normal(0, 0.01, (T, N)), axis=0))
-    tech = rng.normal(0, 50, (T, N * K))
-    turb = np.abs(rng.normal(0, turb_scale, T))
-    cfg = {"price_array": price, "tech_array": tech, "turbulence_array": turb,
-           "if_train": if_train}
-    env = mod.StockTradingEnv(cfg, initial_capital=initial_capital, max_stock=max_stock,
-                              buy_cost_pct=buy_cost_pct, sell_cost_pct=sell_cost_pct, gamma=gamma)
+    raw = {}
+    if nas100:
+        mod = rh._fresh_import("finrl.meta.env_stock_trading.env_nas100_wrds")
+        Traw = T * data_gap
+        raw["raw_price"] = (100 * np.exp(np.cumsum(rng.normal(0, 0.01, (Traw, N)), axis=0))).astype(np.float32)
+        raw["raw_tech"] = rng.normal(0, 50, (Traw, N * K)).astype(np.float32)
+        raw["raw_turb"] = np.abs(rng.normal(0, turb_scale, Traw)).astype(np.float32)
+        env = mod.StockEnvNAS100(cwd=None, price_ary=raw["raw_price"], tech_ary=raw["raw_tech"],
+                                 turbulence_ary=raw["raw_turb"], gamma=gamma,
+                                 turbulence_thresh=turbulence_thresh, max_stock=max_stock,
+                                 initial_capital=initial_capital, buy_cost_pct=buy_cost_pct,
+                                 sell_cost_pct=sell_cost_pct, data_gap=data_gap, if_eval=True)
+        env.stocks_cool_down = None                      # (this class calls it stocks_cd)
+        price, tech, turb = (raw["raw_price"][::data_gap], raw["raw_tech"][::data_gap],
+                             raw["raw_turb"][::data_gap])
+        assert np.array_equal(env.price_ary, price) and env.max_step == T - 1
+        if_train = True                                  # every reset draws its start state
+    else:
+        mod = rh.load_stocktrading_np()
+        price = 100 * np.exp(np.cumsum(rng.normal(0, 0.01, (T, N)), axis=0))
+        tech = rng.normal(0, 50, (T, N * K))
+        turb = np.abs(rng.normal(0, turb_scale, T))
+        cfg = {"price_array": price, "tech_array": tech, "turbulence_array": turb,
+               "if_train": if_train}
+        env = mod.StockTradingEnv(cfg, initial_capital=initial_capital, max_stock=max_stock,
+                                  buy_cost_pct=buy_cost_pct, sell_cost_pct=sell_cost_pct, gamma=gamma)
     act = rng.uniform(-1, 1, (S, N)).astype(np.float32)
     rec = {k: [] for k in ("obs", "reward", "reward_tag", "done", "amount", "amount_tag",
                            "total_asset", "ta_tag", "gamma_reward", "g_tag", "stocks",
@@ -416,7 +438,8 @@ def run_stocknp(name, *, seed, T, N, K, S, if_train=False, initial_capital=1e6, 
         rec["total_asset"].append(float(env.total_asset)); rec["ta_tag"].append(_tag(env.total_asset))
         rec["gamma_reward"].append(float(env.gamma_reward)); rec["g_tag"].append(_tag(env.gamma_reward))
         rec["stocks"].append(np.asarray(env.stocks, np.float32).copy())
-        rec["cool_down"].append(np.asarray(env.stocks_cool_down, np.float32).copy())
+        rec["cool_down"].append(np.asarray(env.stocks_cd if nas100 else env.stocks_cool_down,
+                                           np.float32).copy())
         rec["day"].append(int(env.day))
         rec["episode_return"].append(float(env.episode_return))
         if done:
@@ -433,8 +456,13 @@ def run_stocknp(name, *, seed, T, N, K, S, if_train=False, initial_capital=1e6, 
                reset_amount0_tag=np.asarray(resets["amount0_tag"], np.int64),
                meta=np.array(["variant=O-raw", f"seed={seed}", f"numpy={np.__version__}",
                               "dtype tags: 0=python float, 1=float32, 2=float64",
-                              "source=finrl/meta/env_stock_trading/env_stocktrading_np.py "
-                              "(unmodified)"]))
+                              "source=finrl/meta/env_stock_trading/" +
+                              ("env_nas100_wrds.py" if nas100 else "env_stocktrading_np.py") +
+                              " (unmodified)"]))
+    if nas100:
+        out.update(raw, data_gap=np.array(data_gap, np.int64),
+                   obs_amount_floor=np.array(1e4), turbulence_thresh=np.array(float(turbulence_thresh)),
+                   reset_seed=np.asarray([seed * 1000 + s_ + 7 for s_ in resets["step"]], np.int64))
     for k in ("reward", "amount", "total_asset", "gamma_reward", "episode_return"):
         out[k] = np.asarray(rec[k], np.float64)
     for k in ("reward_tag", "amount_tag", "ta_tag", "g_tag"):
@@ -454,6 +482,12 @@ STOCKNP_SCENARIOS = {
     "train_dow30": dict(seed=53, T=30, N=30, K=8, S=70, if_train=True),
     "eval_n3": dict(seed=54, T=25, N=3, K=2, S=60, initial_capital=5e3, max_stock=50.0,
                     buy_cost_pct=0.002, sell_cost_pct=0.0005, gamma=0.97, turb_scale=90.0),
+    # StockEnvNAS100 (env_nas100_wrds.py): random start at every reset, obs shows max(amount, 1e4);
+    # the poor one keeps the amount under that floor most of the time
+    "nas100_dow30": dict(seed=55, T=30, N=30, K=8, S=70, nas100=True, data_gap=2, gamma=0.999,
+                         turbulence_thresh=30, turb_scale=25.0),
+    "nas100_poor": dict(seed=56, T=24, N=5, K=2, S=55, nas100=True, data_gap=4, gamma=0.999,
+                        turbulence_thresh=30, turb_scale=25.0, initial_capital=3e4),
 }
 
 

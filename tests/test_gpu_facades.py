@@ -165,3 +165,46 @@ def test_sb3_adapter_over_sibling_vec_envs():
                 assert infos[i]["terminal_observation"].shape == (D,)
             seen_done += int(done.sum())
         assert seen_done >= E
+
+
+@pytest.mark.parametrize("name", ["nas100_dow30", "nas100_poor"])
+def test_nas100_facade_replays_reference_episode(name):
+    """StockEnvNAS100 (env_nas100_wrds.py): constructor row selection (cwd=None, if_eval=True,
+    data_gap), the random start state drawn from a seeded numpy.random at every reset, the
+    max(amount, 1e4) observation, attributes the ElegantRL loops read."""
+    _need_gpu()
+    from finrl_amd.meta.env_stock_trading.env_nas100_wrds import StockEnvNAS100
+    z = _load(f"stocknp_{name}.npz")
+    T, N, K, S, _ = z["cfg_int"].tolist()
+    cap, ms, bc, sc, g = z["cfg_float"].tolist()
+    env = StockEnvNAS100(cwd=None, price_ary=z["raw_price"], tech_ary=z["raw_tech"],
+                         turbulence_ary=z["raw_turb"], gamma=g,
+                         turbulence_thresh=float(z["turbulence_thresh"]), max_stock=ms,
+                         initial_capital=cap, buy_cost_pct=bc, sell_cost_pct=sc,
+                         data_gap=int(z["data_gap"]), if_eval=True)
+    assert (env.env_name, env.state_dim, env.action_dim, env.max_step, env.target_return) == \
+        ("StockEnvNAS", 3 + 3 * N + N * K, N, T - 1, 2.2)
+    np.testing.assert_array_equal(env.price_ary, z["price_array"])
+    ri = 0
+
+    def do_reset():
+        nonlocal ri
+        np.random.seed(int(z["reset_seed"][ri]))          # what the fixture generator seeded
+        obs = env.reset()
+        np.testing.assert_array_equal(obs, z["reset_obs"][ri])
+        np.testing.assert_array_equal(env.stocks, z["reset_stocks0"][ri])
+        assert env.amount == z["reset_amount0"][ri] and env.day == 0
+        ri += 1
+
+    do_reset()
+    for s in range(S):
+        obs, rew, done, info = env.step(z["actions"][s])
+        np.testing.assert_array_equal(obs, z["obs"][s])
+        assert rew == np.float32(z["reward"][s]) and done == bool(z["done"][s])
+        assert env.day == z["day"][s] and env.amount == z["amount"][s]
+        np.testing.assert_array_equal(env.stocks, z["stocks"][s])
+        np.testing.assert_array_equal(env.stocks_cd, z["cool_down"][s])
+        if done:
+            assert env.episode_return == z["episode_return"][s]
+            do_reset()
+    assert ri == 3

@@ -31,8 +31,12 @@ def test_stocknp_hip_matches_reference_fixture(name):
     E = 70
     cfg = {"price_array": z["price_array"], "tech_array": z["tech_array"],
            "turbulence_array": z["turbulence_array"], "if_train": False}
+    extra = {}
+    if "obs_amount_floor" in z.files:            # StockEnvNAS100 fixtures (env_nas100_wrds.py)
+        extra = dict(obs_amount_floor=float(z["obs_amount_floor"]),
+                     turbulence_thresh=float(z["turbulence_thresh"]))
     env = VecStockTradingEnvNP(cfg, E, gamma=g, max_stock=ms, initial_capital=cap,
-                               buy_cost_pct=bc, sell_cost_pct=sc, auto_reset=False)
+                               buy_cost_pct=bc, sell_cost_pct=sc, auto_reset=False, **extra)
     ri = 0
 
     def do_reset():

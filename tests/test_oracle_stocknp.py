@@ -16,9 +16,13 @@ NAMES = sorted(os.path.basename(p)[len("stocknp_"):-4]
 def make_oracle(z, n_envs=1):
     from oracle.stocknp import StockNpOracle
     cap, ms, bc, sc, g = z["cfg_float"].tolist()
+    extra = {}
+    if "obs_amount_floor" in z.files:            # StockEnvNAS100 fixtures (env_nas100_wrds.py)
+        extra = dict(obs_amount_floor=float(z["obs_amount_floor"]),
+                     turbulence_thresh=float(z["turbulence_thresh"]))
     return StockNpOracle(z["price_array"], z["tech_array"], z["turbulence_array"],
                          n_envs=n_envs, gamma=g, max_stock=ms, initial_capital=cap,
-                         buy_cost_pct=bc, sell_cost_pct=sc)
+                         buy_cost_pct=bc, sell_cost_pct=sc, **extra)
 
 
 @pytest.mark.parametrize("name", NAMES)
