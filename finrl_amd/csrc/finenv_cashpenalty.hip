@@ -2,9 +2,20 @@
 // (finrl/meta/env_stock_trading/env_stocktrading_cashpenalty.py: step :291-372,
 // get_transactions :249-289, get_reward :237-247, reset :131-157).
 //
-// lane = env, one wave per 64 envs.  No ordering between tickers in this env: transactions
-// are computed per ticker (fp64), two dot products give proceeds / spend, one test decides
-// cash shortage; everything is a short fp64 loop per lane plus the observation row write.
+// lane = env, one 128-thread block per 64 envs, two specialised waves:
+//   wave 0 "trader"  : owns the env state.  No ordering between tickers in this env: transactions
+//                      are computed per ticker (fp64), two dot products give proceeds / spend, one
+//                      test decides cash shortage -- a short fp64 loop per lane.
+//   wave 1 "streamer": gathers every env's next panel row (date + 1, or the known restart row on
+//                      the last date) and writes the market-data chunks of the observation rows
+//                      while the trader computes.  When the trader has decided which episodes end
+//                      (cash shortage) it publishes every env's row through an LDS flag -- no
+//                      barrier, the trader never waits; the streamer then fetches the chunk that
+//                      holds cash / holdings for the decided rows plus the market-data chunks of
+//                      the (rare) re-decided rows and parks chunk 0 in LDS.  After the one hand-off
+//                      barrier both waves store 32 rows of chunk 0 each.
+// One wave used to do both: its 192 row stores alone are 10 us of a 27 us wave (a wave issues one
+// store per ~45 ns), with one wave per SIMD on the chip and the other half of the queue idle.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -26,10 +37,13 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kMaxN = FINENV_CASHPENALTY_MAX_ASSETS;
 constexpr int kRow = kMaxN + 1;
-constexpr int kWaves = 2;
-constexpr int kB = 8;                        // assets per load batch
+constexpr int kWaves = 2;                    // trader + streamer
 constexpr int kClStride = kMaxN + 1;           // f64 close rows [env][33]: odd stride, conflict-free
-constexpr int kLdsPerWave = kWave * kRow + kClStride * kWave * 2 + 2;   // rows + f64 closes [el][i]
+constexpr int kLdsRows = kWave * kRow;         // f32 [el][33]: action tile, then cash / holdings
+constexpr int kLdsClose = kClStride * kWave * 2;   // f64 closes [el][i]
+constexpr int kLdsPerBlock = kLdsRows + kLdsClose + kWave + 2;  // + the rows the trade decided (i32), flag
+constexpr int kFix = 4;                        // re-decided rows per block the streamer patches in registers
+static_assert(kWave * kWave <= kLdsClose, "the parked chunk 0 reuses the close rows");
 
 struct CpParams {
     finenv_cashpenalty_config cfg;
@@ -105,113 +119,74 @@ __device__ __forceinline__ void cp_write_rows(float *__restrict__ dst, const CpP
         [=](int col) { return col <= N ? col : -1; });
 }
 
-// Per-env panel rows (random starts), D <= NCH * 64: every load of the wave's 64 rows is issued
-// before the first store (NCH * 64 VGPRs) -- ONE exposed round trip per wave.  A load placed
-// between stores waits for every older store to be acknowledged (vmcnt is in-order on gfx950).
-template <int NCH>
-__device__ __forceinline__ void cp_write_rows_full(float *__restrict__ dst, const CpParams &p, int e0,
-                                                   int nenv_w, int row_day,
-                                                   unsigned long long lane_mask,
-                                                   const float *rows, int lane)
+// f64 closes of every env's own date into LDS [el][i] (stride kClStride), 64 row loads in flight
+__device__ __forceinline__ void cp_gather_closes(double *trl, const CpParams &p, int di, int lane)
 {
-    const int N = p.cfg.n_assets, D = p.D, W = D - 1 - N;
-    float *const base = dst + (size_t)e0 * D;
-    float t[(NCH > 0 ? NCH : 1) * kWave];
-    if (W > 0) {
+    const int N = p.cfg.n_assets;
+    const int li = min(lane, N - 1);
+    double cv[kWave];
 #pragma unroll
-        for (int el = 0; el < kWave; ++el) {
-            const int de = __builtin_amdgcn_readlane(row_day, el);
-#pragma unroll
-            for (int k = 0; k < NCH; ++k) {
-                const int col = k * kWave + lane;
-                const bool ld = col < D && col > N;
-                t[el * NCH + k] = *at(p.panel.info, (unsigned)(ld ? de * W + col - 1 - N : 0));
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < NCH * kWave; ++j) t[j] = 0.0f;
+    for (int j = 0; j < kWave; ++j) {
+        const int de = __builtin_amdgcn_readlane(di, j);
+        cv[j] = *at(p.panel.close, (unsigned)(de * N + li));
     }
 #pragma unroll
-    for (int j = 0; j < NCH * kWave; ++j) pin(t[j]);
-#pragma unroll
-    for (int el = 0; el < kWave; ++el) {
-        if (el >= nenv_w || !((lane_mask >> el) & 1ull)) continue;
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            const int col = k * kWave + lane;
-            float v = t[el * NCH + k];
-            if (k == 0) {                       // N <= 32: cash / holdings sit in chunk 0 only
-                const bool head = col <= N;
-                const float hv = rows[el * kRow + (head ? col : 0)];
-                v = head ? hv : v;
-            }
-            if (col < D) *at(base, (unsigned)(el * D + col)) = v;
-        }
-    }
+    for (int j = 0; j < kWave; ++j)
+        if (lane < N) trl[j * kClStride + lane] = cv[j];
 }
 
-// The two halves of cp_write_rows_full, so that the 64 x NCH row loads can be issued at the START of
-// the step (right after the day counters arrive, together with the holdings / closes the trade
-// needs) and be in flight during the whole computation: at the end only stores remain.
+// Chunk 0 of rows [el_lo, el_hi): market values parked in LDS ([el][64]) with cash / holdings
+// patched in from rows[].  Only stores towards HBM (LDS reads run ahead of them).
 template <int NCH>
-__device__ __forceinline__ void cp_rows_fetch(float (&t)[(NCH > 0 ? NCH : 1) * kWave],
-                                              const CpParams &p, int row_day, int lane)
+__device__ __forceinline__ void cp_head_store(float *__restrict__ dst, const CpParams &p, int e0,
+                                              int nenv_w, unsigned long long lane_mask,
+                                              const float *rows, const float *park, int lane,
+                                              int el_lo, int el_hi)
 {
-    const int N = p.cfg.n_assets, D = p.D, W = D - 1 - N;
-    if (W <= 0) {                         // no information columns: panel.info may be NULL
+    const int N = p.cfg.n_assets, D = p.D;
+    float *const base = dst + (size_t)e0 * D;
+    const bool head = lane <= N, in = NCH > 1 || lane < D;
+    const unsigned long long want = ((el_hi - el_lo >= 64) ? ~0ull : ((1ull << (el_hi - el_lo)) - 1ull))
+                                    << el_lo;
+    if (nenv_w >= el_hi && (lane_mask & want) == want) {       // all rows: LDS reads 8 rows ahead
+        for (int g = el_lo; g < el_hi; g += 8) {
+            float v[8];
 #pragma unroll
-        for (int j = 0; j < NCH * kWave; ++j) t[j] = 0.0f;
+            for (int j = 0; j < 8; ++j) {
+                const float hv = rows[(g + j) * kRow + (head ? lane : 0)];
+                const float pv = park[(g + j) * kWave + lane];
+                v[j] = head ? hv : pv;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (in) *at(base, (unsigned)((g + j) * D + lane)) = v[j];
+        }
         return;
     }
-#pragma unroll
-    for (int el = 0; el < kWave; ++el) {
-        const int de = __builtin_amdgcn_readlane(row_day, el);
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            const int col = k * kWave + lane;
-            const bool ld = col < D && col > N;
-            t[el * NCH + k] = *at(p.panel.info, (unsigned)(ld ? de * W + col - 1 - N : 0));
-        }
-    }
-}
-
-template <int NCH>
-__device__ __forceinline__ void cp_rows_store(const float (&t)[(NCH > 0 ? NCH : 1) * kWave],
-                                              float *__restrict__ dst, const CpParams &p, int e0,
-                                              int nenv_w, unsigned long long lane_mask,
-                                              const float *rows, int lane)
-{
-    const int N = p.cfg.n_assets, D = p.D, W = D - 1 - N;
-    float *const base = dst + (size_t)e0 * D;
-#pragma unroll
-    for (int el = 0; el < kWave; ++el) {
+    for (int el = el_lo; el < el_hi; ++el) {
         if (el >= nenv_w || !((lane_mask >> el) & 1ull)) continue;
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            const int col = k * kWave + lane;
-            float v = W > 0 ? t[el * NCH + k] : 0.0f;
-            if (k == 0) {                       // N <= 32: cash / holdings sit in chunk 0 only
-                const bool head = col <= N;
-                const float hv = rows[el * kRow + (head ? col : 0)];
-                v = head ? hv : v;
-            }
-            if (col < D) *at(base, (unsigned)(el * D + col)) = v;
-        }
+        const float hv = rows[el * kRow + (head ? lane : 0)];
+        const float v = head ? hv : park[el * kWave + lane];
+        if (in) *at(base, (unsigned)(el * D + lane)) = v;
     }
 }
 
-template <bool RESET_ONLY, int NCH>
-__global__ void __launch_bounds__(kWave *kWaves, 1) cashpenalty_kernel(const CpParams p)
+// (launch bounds: four 2-wave blocks per CU = two waves per SIMD, i.e. at most 256 VGPRs -- at
+//  65,536 envs every block of the grid is then resident at once; DISCRETE = cfg.discrete_actions as
+//  a template flag: with both transaction formulas in one body the step kernel was 66 KB, over the
+//  64 KB instruction cache two CUs share)
+template <bool RESET_ONLY, int NCH, bool DISCRETE>
+__global__ void __launch_bounds__(kWave *kWaves) __attribute__((amdgpu_waves_per_eu(2)))
+cashpenalty_kernel(const CpParams p)
 {
-    __shared__ __attribute__((aligned(16))) float lds_all[kWaves * kLdsPerWave];
+    __shared__ __attribute__((aligned(16))) float lds_all[kLdsPerBlock];
     const int lane = threadIdx.x & (kWave - 1);
-    const int wib = threadIdx.x >> 6;
-    float *rows = lds_all + wib * kLdsPerWave;
-    double *trl = reinterpret_cast<double *>(rows + kWave * kRow + ((kWave * kRow) & 1));
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float *rows = lds_all;
+    double *trl = reinterpret_cast<double *>(lds_all + kLdsRows);
+    int *decided = reinterpret_cast<int *>(lds_all + kLdsRows + kLdsClose);
     const int E = p.cfg.n_envs, N = p.cfg.n_assets;
-    const int e0 = (blockIdx.x * kWaves + wib) * kWave;
-    if (e0 >= E) return;
+    const int e0 = blockIdx.x * kWave;
     const int nenv_w = min(kWave, E - e0);
     const bool valid = lane < nenv_w;
     const int e = valid ? e0 + lane : e0;
@@ -219,6 +194,7 @@ __global__ void __launch_bounds__(kWave *kWaves, 1) cashpenalty_kernel(const CpP
     const finenv_cashpenalty_config &c = p.cfg;
 
     if (RESET_ONLY) {                                                          // :131-157
+        if (role != 0) return;
         const bool sel = valid && (p.mask == nullptr || p.mask[e] != 0);
         const int start = p.rs_hi > 0 ? draw_start(p.rs_seed, e, KI(FINENV_KI_EPISODE) + 1, p.rs_hi)
                                       : KI(FINENV_KI_NEXT_START);
@@ -239,6 +215,110 @@ __global__ void __launch_bounds__(kWave *kWaves, 1) cashpenalty_kernel(const CpP
         return;
     }
 
+    volatile int *const flag = decided + kWave;
+    if (NCH > 0 && role == 0 && lane == 0) *flag = 0;         // (visible after the staging barrier)
+
+    if (role != 0) {
+        // ---- streamer ---------------------------------------------------------------------------
+        if (NCH == 0) return;                 // rows wider than 192 columns: the trader writes them
+        KSTAMP(8);
+        const int W = p.D - 1 - N;
+        const int di_s = KI(FINENV_KI_DATE_INDEX);
+        const bool last = di_s == c.n_days - 1;                                   // :299
+        int ns = 0;
+        if (p.auto_reset && __any(last))
+            ns = p.rs_hi > 0 ? draw_start(p.rs_seed, e, KI(FINENV_KI_EPISODE) + 1, p.rs_hi)
+                             : KI(FINENV_KI_NEXT_START);
+        // the row the next observation shows unless a cash shortage ends the episode here
+        const int row_spec = last ? (p.auto_reset ? ns : di_s) : di_s + 1;
+        cp_gather_closes(trl, p, di_s, lane);
+        lds_barrier();                        // staging barrier: the trader reads its close rows
+        const unsigned long long valid_mask = __ballot(valid);
+        float *const base = p.obs + (size_t)e0 * p.D;
+        if (NCH > 1) {
+            float t[(NCH > 1 ? NCH - 1 : 1) * kWave];
+#pragma unroll
+            for (int el = 0; el < kWave; ++el) {
+                const int de = __builtin_amdgcn_readlane(row_spec, el);
+#pragma unroll
+                for (int k = 1; k < NCH; ++k) {
+                    const int col = k * kWave + lane;
+                    const bool ld = k < NCH - 1 || col < p.D;
+                    t[el * (NCH - 1) + k - 1] = *at(p.panel.info, (unsigned)(ld ? de * W + col - 1 - N : 0));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < (NCH - 1) * kWave; ++j) pin(t[j]);
+            KSTAMP(9);
+#pragma unroll
+            for (int el = 0; el < kWave; ++el) {
+                if (el >= nenv_w) continue;
+#pragma unroll
+                for (int k = 1; k < NCH; ++k) {
+                    const int col = k * kWave + lane;
+                    if (k < NCH - 1 || col < p.D) *at(base, (unsigned)(el * p.D + col)) = t[el * (NCH - 1) + k - 1];
+                }
+            }
+        }
+        KSTAMP(10);
+        while (*flag == 0) __builtin_amdgcn_s_sleep(2);       // the trader has decided every env's row
+        asm volatile("" ::: "memory");
+        const int dec = decided[lane];
+        const unsigned long long fix = __ballot(valid && dec != row_spec);
+        const int nfix = __builtin_popcountll(fix);
+        float t0[kWave];
+        float tf[kFix * (NCH > 1 ? NCH - 1 : 1)];
+        if (W > 0) {
+#pragma unroll
+            for (int el = 0; el < kWave; ++el) {
+                const int de = __builtin_amdgcn_readlane(dec, el);
+                const bool ld = lane > N && (NCH > 1 || lane < p.D);
+                t0[el] = *at(p.panel.info, (unsigned)(ld ? de * W + lane - 1 - N : 0));
+            }
+            if (NCH > 1 && nfix > 0) {
+                unsigned long long m = fix;
+#pragma unroll
+                for (int j = 0; j < kFix; ++j) {
+                    const int el = m != 0ull ? __builtin_ctzll(m) : 0;
+                    m &= m - 1ull;
+                    const int de = __builtin_amdgcn_readlane(dec, el);
+#pragma unroll
+                    for (int k = 1; k < NCH; ++k) {
+                        const int col = k * kWave + lane;
+                        const bool ld = k < NCH - 1 || col < p.D;
+                        tf[j * (NCH - 1) + k - 1] = *at(p.panel.info, (unsigned)(ld ? de * W + col - 1 - N : 0));
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int el = 0; el < kWave; ++el) t0[el] = 0.0f;
+        }
+        float *const park = reinterpret_cast<float *>(trl);      // (the trader is done with the closes)
+#pragma unroll
+        for (int el = 0; el < kWave; ++el) park[el * kWave + lane] = t0[el];
+        KSTAMP(11);
+        lds_barrier();                        // cash / holdings are published; chunk 0 is parked
+        cp_head_store<NCH>(p.obs, p, e0, nenv_w, valid_mask, rows, park, lane, kWave / 2, kWave);
+        if (NCH > 1 && nfix > 0 && W > 0) {
+            unsigned long long m = fix;
+#pragma unroll
+            for (int j = 0; j < kFix; ++j) {
+                if (m == 0ull) continue;
+                const int el = __builtin_ctzll(m);
+                m &= m - 1ull;
+#pragma unroll
+                for (int k = 1; k < NCH; ++k) {
+                    const int col = k * kWave + lane;
+                    if (k < NCH - 1 || col < p.D) *at(base, (unsigned)(el * p.D + col)) = tf[j * (NCH - 1) + k - 1];
+                }
+            }
+            if (m != 0ull) cp_write_rows<true>(p.obs, p, e0, nenv_w, dec, m, rows, lane);
+        }
+        KSTAMP(12);
+        return;
+    }
+
     KSTAMP(0);
     // ---- round trip 1: per-env scalars (the action tile is issued behind them) ----------------
     int di = KI(FINENV_KI_DATE_INDEX);
@@ -247,36 +327,27 @@ __global__ void __launch_bounds__(kWave *kWaves, 1) cashpenalty_kernel(const CpP
     double turb = c.use_turbulence ? KF(FINENV_KF_TURBULENCE) : 0.0;
     double sum_trades = KF(FINENV_KF_SUM_TRADES);
     double logged_total = KF(FINENV_KF_LOGGED_TOTAL), logged_cash = KF(FINENV_KF_LOGGED_CASH);
-    stage_action_tile(rows, kRow, p.actions + (size_t)e0 * N, nenv_w, N, p.magicN, lane);
-    const int step = di - start;                                                 // current_step
-    const bool at_end = di == c.n_days - 1;                                      // :299
-    const unsigned cb = (unsigned)(di * N);
-    // ---- round trip 2, issued at once: holdings and closes of every asset, kept in registers (the
-    // first form fetched them in four dependent batches of 8 and read the holdings a second time
-    // for the book update: 12 us of a 28 us step) ---------------------------------------------------
+    // holdings of every asset, kept in registers (issued behind the scalars: one round trip together
+    // with the action tile; the first form fetched them in four dependent batches of 8 and read
+    // them a second time for the book update: 12 us of a 28 us step)
     double hb[kMaxN], clb[kMaxN];
 #pragma unroll
     for (int i = 0; i < kMaxN; ++i) hb[i] = KH(min(i, N - 1));
+    stage_action_tile(rows, kRow, p.actions + (size_t)e0 * N, nenv_w, N, p.magicN, lane);
+    const int step = di - start;                                                 // current_step
+    const bool at_end = di == c.n_days - 1;                                      // :299
     // closes: every env sits on its own date (random starts), so a per-lane load touches 64
     // different rows per instruction.  Row-wise instead: lane i < N loads close[date_el][i] for one
-    // env el per instruction (one 8N-byte segment), 16 rows in flight, parked in LDS [el][i]; each
-    // lane then reads its own row back.
-    {
-        const int li = min(lane, N - 1);
-        for (int g = 0; g < kWave; g += 16) {
-            double cv[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int de = __builtin_amdgcn_readlane(di, g + j);
-                cv[j] = *at(p.panel.close, (unsigned)(de * N + li));
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (lane < N) trl[(g + j) * kClStride + lane] = cv[j];
-        }
+    // env el per instruction (one 8N-byte segment), all 64 rows in flight, parked in LDS [el][i];
+    // each lane then reads its own row back.  The STREAMER does this gather (it needs the dates
+    // anyway) while the trader's own loads are in flight: the date -> close-row dependency is off
+    // the trader's path, which meets the streamer at the staging barrier.
+    if (NCH == 0) {
+        cp_gather_closes(trl, p, di, lane);
+        wave_sync();
+    } else {
+        lds_barrier();
     }
-    (void)cb;
-    wave_sync();
 #pragma unroll
     for (int i = 0; i < kMaxN; ++i) clb[i] = trl[lane * kClStride + min(i, N - 1)];
     KSTAMP(1);
@@ -302,7 +373,7 @@ __global__ void __launch_bounds__(kWave *kWaves, 1) cashpenalty_kernel(const CpP
             const float a32 = act[i] * hmaxf;                                    // :257 (float32)
             const float a = cl > 0.0 ? a32 : 0.0f;                               // :260
             double tr;
-            if (c.discrete_actions) {                                            // :263-274
+            if (DISCRETE) {                                                      // :263-274
                 // integer-valued doubles instead of int64 arithmetic (exact below 2^53; a software
                 // 64-bit division per asset, unrolled, was 30 KB of code)
                 const double q = cp_floordiv((double)a, cl);
@@ -312,7 +383,9 @@ __global__ void __launch_bounds__(kWave *kWaves, 1) cashpenalty_kernel(const CpP
             } else {
                 tr = (double)a / cl;                                             // :276
             }
-            tr = fmax(tr, -h);                                                   // :279
+            // :279 np.maximum(tr, -h) as compare + select (fmax() quiets both operands first: three
+            // extra fp64 instructions per asset at 8 cycles each); a NaN tr (close == 0) gives -h like fmax
+            tr = !(tr >= -h) ? -h : tr;
             tr = turbulent ? -h : tr;                                            // :282-287
             tr_[i] = tr;
             proceeds += (tr < 0.0 ? -tr : 0.0) * cl;                             // :323-324
@@ -356,17 +429,18 @@ __global__ void __launch_bounds__(kWave *kWaves, 1) cashpenalty_kernel(const CpP
         }
     }
     const bool advance = !done;
-    // ---- the row of the panel each env's next observation shows is known from here on: date + 1,
-    // the unchanged date on a terminal step, or the new starting point on an auto-reset.  Its 64 x
-    // NCH market values are fetched NOW, before this wave's first store (a load issued behind
-    // stores waits for their acknowledgement), and fly during the book update / state stores ------
+    // ---- the row of the panel each env's next observation shows: date + 1, the unchanged date on a
+    // terminal step, or the new starting point on an auto-reset ----------------------------------
     int ns_reset = 0;
     if (p.auto_reset && __any(done))
         ns_reset = p.rs_hi > 0 ? draw_start(p.rs_seed, e, KI(FINENV_KI_EPISODE) + 1, p.rs_hi)
                                : KI(FINENV_KI_NEXT_START);
     const int row_final = done ? (p.auto_reset ? ns_reset : di) : di + 1;
-    float trow[(NCH > 0 ? NCH : 1) * kWave];
-    if (NCH > 0) cp_rows_fetch<NCH>(trow, p, row_final, lane);
+    if (NCH > 0) {                            // publish (LDS is in-order per wave: rows first, then the flag)
+        decided[lane] = row_final;
+        asm volatile("" ::: "memory");
+        *flag = 1;
+    }
     if (advance) {
         coh = coh_new;
 #pragma unroll
@@ -424,7 +498,9 @@ __global__ void __launch_bounds__(kWave *kWaves, 1) cashpenalty_kernel(const CpP
     }
     KSTAMP(4);
     if (NCH > 0) {
-        cp_rows_store<NCH>(trow, p.obs, p, e0, nenv_w, valid_mask, rows, lane);   // (row_day == row_final)
+        lds_barrier();                        // chunk 0 is parked: rows 0..31 here, 32..63 by the streamer
+        cp_head_store<NCH>(p.obs, p, e0, nenv_w, valid_mask, rows,
+                           reinterpret_cast<const float *>(trl), lane, 0, kWave / 2);
     } else {
         cp_write_rows(p.obs, p, e0, nenv_w, row_day, valid_mask, rows, lane);
     }
@@ -481,11 +557,7 @@ CpParams kp_params(const finenv_cashpenalty *h)
     p.audit = h->audit;
     return p;
 }
-dim3 kp_grid(int E)
-{
-    const int waves = (E + kWave - 1) / kWave;
-    return dim3((unsigned)((waves + kWaves - 1) / kWaves));
-}
+dim3 kp_grid(int E) { return dim3((unsigned)((E + kWave - 1) / kWave)); }
 }  // namespace
 
 extern "C" {
@@ -559,7 +631,7 @@ int finenv_cashpenalty_reset(finenv_cashpenalty *h, const uint8_t *mask, float *
     CpParams p = kp_params(h);
     p.mask = mask;
     p.obs = obs_out;
-    hipLaunchKernelGGL((cashpenalty_kernel<true, 0>), kp_grid(h->cfg.n_envs), dim3(kWave * kWaves),
+    hipLaunchKernelGGL((cashpenalty_kernel<true, 0, false>), kp_grid(h->cfg.n_envs), dim3(kWave * kWaves),
                        0, (hipStream_t)stream, p);
     return kp_check(h, "cashpenalty_reset");
 }
@@ -584,12 +656,23 @@ int finenv_cashpenalty_step(finenv_cashpenalty *h, const float *actions, float *
     p.dbg = g_finenv_dbg;
 #endif
     const dim3 grid = kp_grid(h->cfg.n_envs), block(kWave * kWaves);
-    switch ((h->D + kWave - 1) / kWave) {      // chunks per observation row
-    case 1: hipLaunchKernelGGL((cashpenalty_kernel<false, 1>), grid, block, 0, (hipStream_t)stream, p); break;
-    case 2: hipLaunchKernelGGL((cashpenalty_kernel<false, 2>), grid, block, 0, (hipStream_t)stream, p); break;
-    case 3: hipLaunchKernelGGL((cashpenalty_kernel<false, 3>), grid, block, 0, (hipStream_t)stream, p); break;
-    default: hipLaunchKernelGGL((cashpenalty_kernel<false, 0>), grid, block, 0, (hipStream_t)stream, p); break;
+    const int nch = (h->D + kWave - 1) / kWave;      // chunks per observation row
+#define CP_LAUNCH(NCH_)                                                                          \
+    do {                                                                                         \
+        if (h->cfg.discrete_actions)                                                             \
+            hipLaunchKernelGGL((cashpenalty_kernel<false, NCH_, true>), grid, block, 0,          \
+                               (hipStream_t)stream, p);                                          \
+        else                                                                                     \
+            hipLaunchKernelGGL((cashpenalty_kernel<false, NCH_, false>), grid, block, 0,         \
+                               (hipStream_t)stream, p);                                          \
+    } while (0)
+    switch (nch) {
+    case 1: CP_LAUNCH(1); break;
+    case 2: CP_LAUNCH(2); break;
+    case 3: CP_LAUNCH(3); break;
+    default: CP_LAUNCH(0); break;
     }
+#undef CP_LAUNCH
     return kp_check(h, "cashpenalty_step");
 }
 

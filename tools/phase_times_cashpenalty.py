@@ -34,12 +34,15 @@ def main():
         acc.append(buf.cpu().numpy().reshape(nw, 16).astype(np.float64) * 0.01)
     a = np.stack(acc)
     rel = a - a[:, :, 0].min(axis=1)[:, None, None]
-    names = ["start", "tile + state staged", "transactions computed", "books updated",
-             "reward / state scalars stored", "obs rows written"]
-    print(f"cashpenalty E={E} waves={nw}; us since the first wave started (median; p95)")
-    for k, n in enumerate(names):
+    names = {0: "trader: start", 1: "trader: tile + state staged", 2: "trader: transactions computed",
+             3: "trader: books updated", 4: "trader: at the hand-off barrier",
+             5: "trader: its half of chunk 0 stored", 8: "streamer: start", 9: "streamer: market-data chunks fetched",
+             10: "streamer: market-data chunks stored", 11: "streamer: chunk 0 parked",
+             12: "streamer: its half of chunk 0 stored"}
+    print(f"cashpenalty E={E} blocks={nw}; us since the first wave started (median; p95)")
+    for k, n in names.items():
         v = rel[:, :, k].reshape(-1)
-        print(f"  {k} {n:32s} {np.median(v):7.2f}  [{np.percentile(v, 95):7.2f}]")
+        print(f"  {k:2d} {n:40s} {np.median(v):7.2f}  [{np.percentile(v, 95):7.2f}]")
 
 if __name__ == "__main__":
     main()
