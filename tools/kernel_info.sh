@@ -23,8 +23,11 @@ for ln in sys.stdin:
     if t.startswith("LDS Size") and name:
         print("%-84s vgpr %3s agpr %3s scratch %4s sgpr-spill %3s lds %6s occ %s" % (name[:84], d.get("vgpr"), d.get("agpr"), d.get("scratch"), d.get("sspill"), d.get("lds"), d.get("occ")))
 '
-# code sizes (bytes) of the same kernels
+# code sizes (bytes) of the same kernels: compile to an object, unbundle the gfx950 code object
 tmp=$(mktemp -d); trap 'rm -rf $tmp' EXIT
-( cd $tmp && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off \
-    -I$OLDPWD/../../include -I$OLDPWD "$@" -c -save-temps -o x.o $OLDPWD/$src >/dev/null 2>&1 || true
-  /opt/rocm/lib/llvm/bin/llvm-readelf -s *gfx950.out 2>/dev/null | awk '$4=="FUNC" && !seen[$8]++ {printf "  code %6d B  %s\n", $3, substr($8,1,100)}' )
+B=/opt/rocm/lib/llvm/bin
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -I. "$@" \
+    -c -o $tmp/x.o "$src" >/dev/null 2>&1
+$B/llvm-objcopy --dump-section .hip_fatbin=$tmp/fb.bin $tmp/x.o
+$B/clang-offload-bundler --unbundle --type=o --input=$tmp/fb.bin --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=$tmp/co.elf
+$B/llvm-readelf -s $tmp/co.elf | awk '$4=="FUNC" && !seen[$8]++ {printf "  code %6d B  %s\n", $3, substr($8,1,100)}'

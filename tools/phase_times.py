@@ -16,6 +16,7 @@ os.environ.setdefault("FINENV_LIB", os.path.join(ROOT, "finrl_amd", "lib", "libf
 def main():
     E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
     NT = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+    desync = len(sys.argv) > 3 and sys.argv[3] == "desync"
     import torch
     import bench
     from finrl_amd import StockPanel, _native as nat
@@ -23,6 +24,10 @@ def main():
     close, tech, risk = bench.synth_panel(N=NT)
     env = VecStockTradingEnv(StockPanel(close, tech, risk), E, **bench.ENV_KW)
     env.reset()
+    if desync:          # every env on its own day, like bench.py --desync
+        offs = torch.randint(0, close.shape[0] - 1, (E,), device="cuda").to(torch.int32)
+        for k in ("day", "price_day", "start_day"):
+            env.state[k].copy_(offs)
     nb = (E + 63) // 64
     buf = torch.zeros(nb * 2 * 16, dtype=torch.int64, device="cuda")
     pool = [torch.rand(E, NT, device="cuda") * 2 - 1 for _ in range(8)]
@@ -45,19 +50,27 @@ def main():
                "obs chunk0 written", "state written"]
     names_s = ["start", "day/pd loaded", "tile+prices staged", "barrier passed", "streamed",
                "hand-off chunk written"]
-    print(f"E={E} blocks={nb}; times in us since the first wave of the launch started "
+    print(f"E={E} blocks={nb}{' desynchronised days' if desync else ''}; times in us since the first wave of the launch started "
           "(median over blocks and 20 launches; p95 in brackets)")
     print("trader wave:")
     for k, n in enumerate(names_t):
         v = rel[:, :, 0, k].reshape(-1)
-        print(f"  {k:2d} {n:24s} {np.median(v):7.2f}  [{np.percentile(v, 95):7.2f}]")
+        print(f"  {k:2d} {n:24s} {np.median(v):7.2f}  [{np.percentile(v, 95):7.2f}]  p99 {np.percentile(v, 99):6.2f}  max {v.max():6.2f}")
     print("streamer wave:")
     for k, n in enumerate(names_s):
         v = rel[:, :, 1, k].reshape(-1)
-        print(f"  {k:2d} {n:24s} {np.median(v):7.2f}  [{np.percentile(v, 95):7.2f}]")
+        print(f"  {k:2d} {n:24s} {np.median(v):7.2f}  [{np.percentile(v, 95):7.2f}]  p99 {np.percentile(v, 99):6.2f}  max {v.max():6.2f}")
     cyc = (a[:, :, 0, 15] - a[:, :, 0, 14]) / 0.01          # raw shader-clock ticks
     us = a[:, :, 0, 11] - a[:, :, 0, 0]
     print(f"trader shader clock: {np.median(cyc / us) / 1e3:.2f} GHz (s_memtime ticks / s_memrealtime us)")
+    fin = rel[:, :, 0, 11]
+    thr = np.percentile(fin, 98)
+    slow = np.argwhere(fin >= thr)[:, 1]
+    print("slowest 2 % of traders by block index mod 8:", np.bincount(slow % 8, minlength=8).tolist(),
+          " by index quartile:", np.bincount(slow * 4 // nb, minlength=4).tolist())
+    sl = fin >= thr
+    for k in (1, 2, 7, 9, 10):
+        print(f"   slow blocks, trader stamp {k}: median {np.median(rel[:, :, 0, k][sl]):.2f}")
     last = rel[:, :, 0, 11].max(axis=1)
     print(f"last trader finishes at {np.median(last):.2f} us; last streamer at "
           f"{np.median(rel[:, :, 1, 4].max(axis=1)):.2f} us")
