@@ -346,8 +346,8 @@ def build_workload(args, torch, dev, rank):
 def attach_rollout(w, args, torch, dev, gen):
     """BASELINE configs[4]: PPO rollout collection into device-resident [n_steps, E, .] buffers.
     Every step writes obs / reward / done straight into slice t (the C ABI takes output pointers:
-    no staging copy), actions / values / log-probs are copied in from a stand-in policy (random
-    tensors: no network is part of the env path), and every n_steps steps the GAE scan kernel runs
+    no staging copy), actions / values / log-probs of a stand-in policy (random tensors: no network is part of
+    the env path) are stored by one launch (finenv_rollout_put), and every n_steps steps the GAE scan kernel runs
     (finenv_gae_scan).  Still one env step per `step`."""
     from finrl_amd.rollout import RolloutBuffer
     n = int(args.rollout)
@@ -370,9 +370,7 @@ def attach_rollout(w, args, torch, dev, gen):
     state = dict(t=0)
 
     def one(t, i):
-        buf.actions[t].copy_(w.pool[i % len(w.pool)])
-        buf.values[t].copy_(vals[i & 3])
-        buf.log_probs[t].copy_(lps[i & 3])
+        buf.put(t, w.pool[i % len(w.pool)], vals[i & 3], lps[i & 3])
         env.step(buf.actions[t], out=(buf.obs[t + 1], buf.rewards[t], buf.dones[t]))
 
     def finish(i):
@@ -388,9 +386,9 @@ def attach_rollout(w, args, torch, dev, gen):
                 finish(i)
                 t = 0
             state["t"] = t
-        w.config_extra["launch"] = "eager (4 launches per step)"
+        w.config_extra["launch"] = "eager (2 launches per step)"
     else:
-        # a whole segment -- n x (3 buffer copies + env step) + GAE scan + carry-over copy -- is ONE
+        # a whole segment -- n x (policy-output store + env step) + GAE scan + carry-over copy -- is ONE
         # hipGraph: replayed with one host call per n steps (every step() of the envs is a plain
         # launch on the caller's stream: no allocation, sync or host read-back in the C ABI)
         cur = torch.cuda.current_stream(dev)

@@ -25,14 +25,30 @@ class RolloutBuffer:
         self.advantages = torch.zeros(n_steps, num_envs, **kw)
         self.returns = torch.zeros(n_steps, num_envs, **kw)
 
+    def put(self, t, actions, values, log_probs):
+        """Store the policy's outputs of step t (one launch: finenv_rollout_put)."""
+        import torch
+        L = nat.lib()
+        L.finenv_rollout_put.argtypes = [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p]
+        dev = self.rewards.device
+        a = actions.to(dev, torch.float32).contiguous()
+        v = values.to(dev, torch.float32).contiguous()
+        lp = log_probs.to(dev, torch.float32).contiguous()
+        if a.numel() != self.actions[t].numel() or v.numel() != self.num_envs or lp.numel() != self.num_envs:
+            raise ValueError("put: expected actions [E, A], values [E], log_probs [E]")
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        nat.check(L.finenv_rollout_put(
+            C.c_void_p(a.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(lp.data_ptr()),
+            C.c_void_p(self.actions[t].data_ptr()), C.c_void_p(self.values[t].data_ptr()),
+            C.c_void_p(self.log_probs[t].data_ptr()), self.num_envs,
+            self.actions.shape[2], stream), None, "finenv_rollout_put")
+
     def collect(self, env, policy, first_obs):
         """policy(obs) -> (actions [E,A] f32, values [E], log_probs [E]) on device."""
         self.obs[0].copy_(first_obs)
         for t in range(self.n_steps):
             a, v, lp = policy(self.obs[t])
-            self.actions[t].copy_(a)
-            self.values[t].copy_(v)
-            self.log_probs[t].copy_(lp)
+            self.put(t, a, v, lp)
             env.step(self.actions[t], out=(self.obs[t + 1], self.rewards[t], self.dones[t]))
         return self.obs[self.n_steps]
 

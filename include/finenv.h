@@ -304,6 +304,14 @@ int finenv_gae_scan(const float *rewards, const float *values, const uint8_t *do
                     int32_t n_steps, int32_t n_envs, float gamma, float gae_lambda,
                     void *stream);
 
+/* One launch that stores a policy's outputs for step t into the rollout tensors: actions [E][A],
+ * values [E], log-probs [E] (float32, contiguous) -> the three destination slices.  Replaces the
+ * three tensor copies of SB3's RolloutBuffer.add (its obs / reward / done parts need no copy: the
+ * env kernels write them in place). */
+int finenv_rollout_put(const float *actions, const float *values, const float *log_probs,
+                       float *actions_out, float *values_out, float *log_probs_out,
+                       int32_t n_envs, int32_t action_dim, void *stream);
+
 /* =====================================================================================
  * Array-state StockTradingEnv (finrl/meta/env_stock_trading/env_stocktrading_np.py:8-169),
  * the ElegantRL / RLlib-facing env.

@@ -140,13 +140,19 @@ def test_rollout_buffer_and_gae_scan():
     gen = torch.Generator(device="cuda")
     gen.manual_seed(0)
 
+    outs = []
+
     def policy(obs):
         a = torch.rand(E, N, generator=gen, device="cuda") * 2 - 1
-        return a, obs[:, 0] * 0.5 + a.sum(1) * 0.01, -a.abs().sum(1)
+        outs.append((a, obs[:, 0] * 0.5 + a.sum(1) * 0.01, -a.abs().sum(1)))
+        return outs[-1]
 
     first = env.reset()
     orc.reset()
     last_obs = buf.collect(env, policy, first)
+    for t, (a, v, lp) in enumerate(outs):         # the one-launch store of the policy's outputs
+        assert torch.equal(buf.actions[t], a) and torch.equal(buf.values[t], v)
+        assert torch.equal(buf.log_probs[t], lp)
     acts = buf.actions.cpu().numpy()
     for t in range(n_steps):                      # crosses two episode boundaries (auto-reset)
         o_obs, o_rew, o_done, _ = orc.vec_step(acts[t])
@@ -160,3 +166,19 @@ def test_rollout_buffer_and_gae_scan():
                        buf.dones.cpu().numpy(), last_values.cpu().numpy(), 0.99, 0.95)
     np.testing.assert_array_equal(adv.cpu().numpy(), e_adv)
     np.testing.assert_array_equal(ret.cpu().numpy(), e_ret)
+
+
+def test_rollout_put_odd_sizes():
+    """finenv_rollout_put on sizes / offsets that rule out 16-byte accesses (scalar path)."""
+    _need_gpu()
+    from finrl_amd.rollout import RolloutBuffer
+    E, A = 301, 3
+    buf = RolloutBuffer(5, E, 7, A)
+    for t in range(5):
+        a, v, lp = torch.randn(E, A, device="cuda"), torch.randn(E, device="cuda"), torch.randn(E, device="cuda")
+        buf.put(t, a, v, lp)
+        assert torch.equal(buf.actions[t], a) and torch.equal(buf.values[t], v)
+        assert torch.equal(buf.log_probs[t], lp)
+    with pytest.raises(ValueError):
+        buf.put(0, torch.zeros(E, A + 1, device="cuda"), torch.zeros(E, device="cuda"),
+                torch.zeros(E, device="cuda"))
