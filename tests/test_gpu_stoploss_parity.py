@@ -74,7 +74,13 @@ def test_stoploss_hip_matches_reference_fixture(name):
     dict(E=1000, T=30, N=30, C=5, steps=80, hmax=4_000, thr=50.0, patient=False, disc=False),
     dict(E=130, T=20, N=5, C=2, steps=50, hmax=300_000, thr=None, patient=True, disc=False),
     dict(E=65, T=16, N=32, C=1, steps=40, hmax=6_000, thr=45.0, patient=False, disc=True),
-    dict(E=64, T=10, N=1, C=0, steps=25, hmax=9e5, thr=30.0, patient=False, disc=False)])
+    dict(E=64, T=10, N=1, C=0, steps=25, hmax=9e5, thr=30.0, patient=False, disc=False),
+    # nearly every env runs out of cash within a few steps: many more re-decided rows per block than
+    # the streamer patches in registers, rows on three observation chunks, 17..30 assets in its pass 3
+    dict(E=200, T=40, N=30, C=5, steps=30, hmax=400_000, thr=None, patient=False, disc=False),
+    dict(E=257, T=40, N=20, C=4, steps=60, hmax=30_000, thr=60.0, patient=True, disc=True),
+    # rows wider than 192 columns: the one-wave kernel
+    dict(E=100, T=20, N=30, C=7, steps=30, hmax=60_000, thr=40.0, patient=False, disc=True)])
 def test_stoploss_hip_matches_oracle_random_batch(cfg):
     _need_gpu()
     from finrl_amd.vec_cashpenalty import CashPenaltyPanel, VecStopLossEnv
