@@ -263,7 +263,8 @@ def build_workload(args, torch, dev, rank):
         w.kernel = "stock_step_wide_kernel" if (N == 100 and ENV_KW["hmax"] <= 255) else "stock_step_kernel"
         w.traffic = stock_traffic(E, N, thr, args.desync)
         w.episode_len = None if args.desync else T
-        w.config_extra = dict(tickers=N, indicators=K, days=T, track_stats=not args.no_stats)
+        w.config_extra = dict(tickers=N, indicators=K, days=T, track_stats=not args.no_stats,
+                              obs_row_pitch_floats=int(w.env.obs.stride(0)))
         w.action_dim = N
         if args.desync:     # every env on its own day: defeats the panel-row broadcast
             def _desync():

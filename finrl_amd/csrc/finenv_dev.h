@@ -298,10 +298,11 @@ __device__ __forceinline__ void head_plan(HeadPlan<KP> &hp, const float *ldst, i
 
 template <int KP, typename Val>
 __device__ __forceinline__ void head_store(const HeadPlan<KP> &hp, float *__restrict__ dst, int D,
-                                           int e0, int nenv_w, unsigned long long lane_mask,
+                                           int P, int e0, int nenv_w, unsigned long long lane_mask,
                                            int lane, int el_lo, int el_hi, Val val)
 {
-    float *const base = dst + (size_t)e0 * D;
+    (void)D;                                  // P: row pitch of dst in floats (>= D)
+    float *const base = dst + (size_t)e0 * P;
     const int hi = min(nenv_w, el_hi);
     // batches of kB rows: the batch's LDS reads are all in flight before its first store (one row
     // at a time exposes an LDS round trip per row: ~170 cycles x 64 rows at the tail of every block)
@@ -319,7 +320,7 @@ __device__ __forceinline__ void head_store(const HeadPlan<KP> &hp, float *__rest
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
                 const float v = hp.w[k] >= 0 ? pv[j][k] : hp.t[k];
-                if (hp.in[k]) *at(base, (unsigned)(el * D + k * kWaveSize + lane)) = v;
+                if (hp.in[k]) *at(base, (unsigned)(el * P + k * kWaveSize + lane)) = v;
             }
         }
     }

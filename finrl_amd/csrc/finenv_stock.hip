@@ -67,6 +67,7 @@ struct finenv_stock {
     finenv_stock_state st;
     int bound;
     int D;
+    int obs_pitch;        // row pitch of the obs buffers handed to step / reset / observe (floats)
     uint32_t magicN;
     char err[256];
 };
@@ -97,6 +98,7 @@ Params make_params(const finenv_stock *h)
     p.panel = h->panel;
     p.st = h->st;
     p.D = h->D;
+    p.obs_pitch = h->obs_pitch;
     p.magicN = h->magicN;
     return p;
 }
@@ -202,6 +204,7 @@ int finenv_stock_create(const finenv_stock_config *cfg, finenv_stock **out)
     h->device = -1;
     h->cfg = *cfg;
     h->D = 1 + 2 * cfg->n_tickers + cfg->n_tech * cfg->n_tickers;
+    h->obs_pitch = h->D;
     h->magicN = cfg->n_tickers >= 2
                     ? (uint32_t)(((1ull << 32) + cfg->n_tickers - 1) / (unsigned)cfg->n_tickers)
                     : 0u;
@@ -214,6 +217,16 @@ void finenv_stock_destroy(finenv_stock *h) { delete h; }
 const char *finenv_stock_last_error(const finenv_stock *h) { return h ? h->err : "null handle"; }
 
 int finenv_stock_obs_dim(const finenv_stock *h) { return h ? h->D : FINENV_ERR_INVALID; }
+
+int finenv_stock_set_obs_pitch(finenv_stock *h, int32_t pitch)
+{
+    if (!h) return FINENV_ERR_INVALID;
+    if (pitch == 0) pitch = h->D;
+    if (pitch < h->D || (long long)pitch * 64 * 4 > (1ll << 32) - 1)
+        return fail(h, FINENV_ERR_INVALID, "set_obs_pitch: pitch must be >= obs_dim");
+    h->obs_pitch = pitch;
+    return FINENV_OK;
+}
 
 int finenv_stock_bind(finenv_stock *h, const finenv_stock_panel *panel,
                       const finenv_stock_state *st)

@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
             head_plan(hp, ldshead, p.D, rd, __builtin_amdgcn_readfirstlane(rd), vm, lane, kpatch,
                       head_widx);
             if (hp.uniform)
-                head_store(hp, p.obs, p.D, e0, nenv_w, vm, lane, kWave / 2, kWave,
+                head_store(hp, p.obs, p.D, p.D, e0, nenv_w, vm, lane, kWave / 2, kWave,
                            [heads](int el, int w) { return heads[el * kRowH + w]; });
             else
                 np_write_rows(p.obs, p, e0, nenv_w, rd, vm & 0xFFFFFFFF00000000ull, heads, lane, 0,
@@ -545,7 +545,7 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
         HeadPlan<kHeadMax> hp;
         head_plan(hp, ldshead, p.D, row_day, day0, valid_mask, lane, kpatch, head_widx);
         if (done_mask == 0ull && hp.uniform)
-            head_store(hp, p.obs, p.D, e0, nenv_w, valid_mask, lane, 0, kWave / 2,
+            head_store(hp, p.obs, p.D, p.D, e0, nenv_w, valid_mask, lane, 0, kWave / 2,
                        [heads](int el, int w) { return heads[el * kRowH + w]; });
         else
             np_write_rows(p.obs, p, e0, nenv_w, row_day,

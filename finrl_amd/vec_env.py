@@ -12,6 +12,7 @@ only owns the torch tensors that back the state and hands their pointers over.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -43,7 +44,7 @@ class VecStockTradingEnv:
                  initial_amount=1_000_000, num_stock_shares=None, buy_cost_pct=1e-3,
                  sell_cost_pct=1e-3, reward_scaling=1e-4, turbulence_threshold=None,
                  day=0, initial=True, reset_quirk=True, track_stats=True, auto_reset=True,
-                 device="cuda"):
+                 device="cuda", obs_pitch=None):
         torch = _torch()
         if not isinstance(buy_cost_pct, (int, float)) or not isinstance(sell_cost_pct, (int, float)):
             # the fork's own env raises TypeError on list costs
@@ -97,7 +98,25 @@ class VecStockTradingEnv:
         sp = nat.StockStatePtrs(self._state_f64.data_ptr(), self._state_i32.data_ptr())
         nat.check(L.finenv_stock_bind(self._h, C.byref(pp), C.byref(sp)), self._h, "bind")
 
-        self.obs = torch.zeros(E, panel.D, dtype=torch.float32, device=dev)
+        # Observation rows: `obs` is a [E, D] view of a buffer whose rows start on 64-byte boundaries
+        # (pitch = D rounded up to 16 floats) unless obs_pitch="packed" / an explicit pitch is given:
+        # packed rows of 4*D bytes share their first and last 64-byte segment with a neighbour row
+        # written microseconds apart -- two partial HBM writes instead of one.
+        # Values and shape are the reference's; only the row stride differs (obs.stride(0)).
+        if obs_pitch is None:
+            obs_pitch = os.environ.get("FINENV_OBS_PITCH", "aligned")
+        if obs_pitch == "aligned":
+            pitch = (panel.D + 15) // 16 * 16
+        elif obs_pitch == "packed":
+            pitch = panel.D
+        else:
+            pitch = int(obs_pitch)
+            if pitch < panel.D:
+                raise ValueError("obs_pitch must be >= the observation dimension")
+        self._obs_buf = torch.zeros(E, pitch, dtype=torch.float32, device=dev)
+        self.obs = self._obs_buf[:, :panel.D]
+        self._pitch = self._pitch_set = pitch
+        nat.check(L.finenv_stock_set_obs_pitch(self._h, pitch), self._h, "set_obs_pitch")
         self.reward = torch.zeros(E, dtype=torch.float32, device=dev)
         self.done = torch.zeros(E, dtype=torch.uint8, device=dev)
         self.term_obs = None
@@ -124,8 +143,15 @@ class VecStockTradingEnv:
     def enable_terminal_obs(self):
         torch = _torch()
         if self.term_obs is None:
-            self.term_obs = torch.zeros_like(self.obs)
+            self.term_obs = torch.zeros(self.num_envs, self.state_dim, dtype=torch.float32,
+                                        device=self.device)
         return self.term_obs
+
+    def _use_pitch(self, pitch):
+        if pitch != self._pitch_set:
+            nat.check(nat.lib().finenv_stock_set_obs_pitch(self._h, int(pitch)), self._h,
+                      "set_obs_pitch")
+            self._pitch_set = pitch
 
     def enable_realised(self):
         torch = _torch()
@@ -143,12 +169,14 @@ class VecStockTradingEnv:
             torch = _torch()
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
             mptr = C.c_void_p(mask.data_ptr())
+        self._use_pitch(self._pitch)
         nat.check(L.finenv_stock_reset(self._h, mptr, C.c_void_p(self.obs.data_ptr()),
                                        self._stream()), self._h, "reset")
         return self.obs
 
     def observe(self):
         """render() (:395-396): current observation without stepping."""
+        self._use_pitch(self._pitch)
         nat.check(nat.lib().finenv_stock_observe(self._h, C.c_void_p(self.obs.data_ptr()),
                                                  self._stream()), self._h, "observe")
         return self.obs
@@ -181,8 +209,13 @@ class VecStockTradingEnv:
         ret = (self.obs, self.reward, self.done)
         if out is not None:
             ret = out
+            if out[0].stride(-1) != 1 or tuple(out[0].shape) != tuple(self.obs.shape):
+                raise ValueError("out[0] must be [E, D] float32 with unit column stride")
+            self._use_pitch(out[0].stride(0))
             outs = (C.c_void_p(out[0].data_ptr()), C.c_void_p(out[1].data_ptr()),
                     C.c_void_p(out[2].data_ptr())) + outs[3:]
+        elif self._pitch_set != self._pitch:
+            self._use_pitch(self._pitch)
         rc = fn(self._h, C.c_void_p(actions.data_ptr()), *outs, int(self.auto_reset),
                 self._stream())
         if rc:

@@ -149,6 +149,14 @@ void finenv_stock_destroy(finenv_stock *h);
 const char *finenv_stock_last_error(const finenv_stock *h);
 int  finenv_stock_obs_dim(const finenv_stock *h);
 
+/* Row pitch, in floats, of the observation buffers later handed to step / reset / observe
+ * (terminal observations stay packed).  Default = obs_dim (packed [E][D] rows, what the reference
+ * returns); 0 restores it.  A pitch that is a multiple of 16 floats starts every row on a 64-byte
+ * boundary: packed rows of 1204 B share their first and last 64-B segment with a neighbour that
+ * is written ~13 us earlier or later (two partial HBM writes instead of one; PMC: 1.05x the bytes
+ * stored).  The consumer sees a [E][D] view with a row stride. */
+int  finenv_stock_set_obs_pitch(finenv_stock *h, int32_t pitch);
+
 /* Attach the panel and state buffers (replaces self.df / self.state ownership). */
 int finenv_stock_bind(finenv_stock *h, const finenv_stock_panel *panel,
                       const finenv_stock_state *state);

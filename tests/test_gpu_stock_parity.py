@@ -294,3 +294,46 @@ def test_gym_facade_is_drop_in(name, capsys):
     assert tj == 2
     printed = capsys.readouterr().out
     assert printed == str(z["printed"]), "episode summary text differs from the reference's"
+
+
+@pytest.mark.parametrize("N,K", [(30, 8), (100, 2), (50, 3)])
+def test_obs_row_pitch_changes_only_the_stride(N, K):
+    """obs is a [E, D] view whose rows start on 64-byte boundaries by default
+    (finenv_stock_set_obs_pitch); "packed" gives the reference's contiguous rows; `out=` takes any
+    row stride.  Same values in all three, across terminal steps and auto-resets."""
+    _need_gpu()
+    from finrl_amd import StockPanel
+    E, T = 200, 9
+    close, tech, risk = _random_panel(3, T, N, K)
+    panel = StockPanel(close, tech, risk)
+    kw = dict(hmax=100, initial_amount=300_000, turbulence_threshold=50.0)
+    a_env = _make_env(panel, E, **kw)
+    p_env = _make_env(panel, E, obs_pitch="packed", **kw)
+    o_env = _make_env(panel, E, obs_pitch=panel.D + 3, **kw)
+    D = panel.D
+    assert a_env.obs.stride(0) % 16 == 0 and a_env.obs.stride(0) >= D and a_env.obs.shape == (E, D)
+    assert p_env.obs.is_contiguous() and o_env.obs.stride(0) == D + 3
+    out_buf = torch.full((E, D + 40), -7.0, device="cuda")
+    out = (out_buf[:, :D], torch.zeros(E, device="cuda"), torch.zeros(E, dtype=torch.uint8, device="cuda"))
+    x_env = _make_env(panel, E, **kw)
+    for env in (a_env, p_env, o_env, x_env):
+        env.enable_terminal_obs()
+    ref = p_env.reset().clone()
+    assert torch.equal(a_env.reset(), ref) and torch.equal(o_env.reset(), ref)
+    x_env.reset()
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1)
+    for s in range(2 * T + 3):
+        a = torch.rand(E, N, generator=gen, device="cuda") * 2 - 1
+        po, pr, pdn, _ = p_env.step(a)
+        for env in (a_env, o_env):
+            o, r, d, _ = env.step(a)
+            assert torch.equal(o, po) and torch.equal(r, pr) and torch.equal(d, pdn), s
+            assert torch.equal(env.term_obs, p_env.term_obs)
+        o, r, d, _ = x_env.step(a, out=out)
+        assert torch.equal(o, po) and torch.equal(r, pr) and torch.equal(d, pdn)
+        assert bool((out_buf[:, D:] == -7.0).all())          # nothing written past the row
+        if s == 3:                                           # back to its own buffer and pitch
+            o2 = x_env.observe()
+            assert torch.equal(o2, po)
+    assert bool((a_env._obs_buf[:, D:] == 0).all())
