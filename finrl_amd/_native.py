@@ -216,6 +216,7 @@ def lib():
     L.finenv_stocknp_last_error.argtypes = [C.c_void_p]
     L.finenv_stocknp_last_error.restype = C.c_char_p
     L.finenv_stocknp_obs_dim.argtypes = [C.c_void_p]
+    L.finenv_stocknp_set_obs_pitch.argtypes = [C.c_void_p, C.c_int32]
     L.finenv_stocknp_bind.argtypes = [C.c_void_p, C.POINTER(StockNpPanelPtrs),
                                       C.POINTER(StockNpStatePtrs)]
     L.finenv_stocknp_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

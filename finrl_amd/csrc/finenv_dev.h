@@ -110,15 +110,17 @@ __device__ __forceinline__ void write_obs_rows_generic(float *__restrict__ dst,
                                                        const float *heads, int head_stride,
                                                        int lane, TmplIndex tmpl_index,
                                                        PatchSel patch_sel, int k_lo = 0,
-                                                       int k_hi = 1 << 30)
+                                                       int k_hi = 1 << 30, int pitch = 0)
 {
     // [k_lo, k_hi): chunk range to write (a streamer wave takes the pure market-data chunks)
+    // pitch: row pitch of dst in floats (0 = packed rows of D floats)
     if (lane_mask == 0ull) return;
+    const int P = pitch > 0 ? pitch : D;
     const int first = __builtin_ctzll(lane_mask);
     const int d0 = __builtin_amdgcn_readlane(row_day, first);
     const bool mine = (lane_mask >> lane) & 1ull;
     const bool uniform = __all(!mine || row_day == d0);
-    float *const base = dst + (size_t)e0 * D;
+    float *const base = dst + (size_t)e0 * P;
     const int nchunk = min(k_hi, (D + kWaveSize - 1) / kWaveSize);
     if (k_lo >= nchunk) return;
 
@@ -134,7 +136,7 @@ __device__ __forceinline__ void write_obs_rows_generic(float *__restrict__ dst,
                 float v = 0.0f;
                 if (tmpl != nullptr && idx >= 0) v = *at(tmpl, (unsigned)idx);
                 if (s >= 0) v = heads[el * head_stride + s];
-                if (in) *at(base, (unsigned)(el * D + col)) = v;
+                if (in) *at(base, (unsigned)(el * P + col)) = v;
             }
         }
         return;
@@ -172,7 +174,7 @@ __device__ __forceinline__ void write_obs_rows_generic(float *__restrict__ dst,
                 for (int k = 0; k < kMaxChunks; ++k) {
                     if (k_lo + k >= nchunk) break;
                     const int col = (k_lo + k) * kWaveSize + lane;
-                    if (col < D) *at(base, (unsigned)(el * D + col)) = t[k];
+                    if (col < D) *at(base, (unsigned)(el * P + col)) = t[k];
                 }
             }
             return;
@@ -199,7 +201,7 @@ __device__ __forceinline__ void write_obs_rows_generic(float *__restrict__ dst,
                     if (k_lo + k >= nchunk) break;
                     const int col = (k_lo + k) * kWaveSize + lane;
                     const float v = (anyp[k] && sel[k] >= 0) ? hv[j][k] : t[k];
-                    if (col < D) *at(base, (unsigned)(el * D + col)) = v;
+                    if (col < D) *at(base, (unsigned)(el * P + col)) = v;
                 }
             }
         }
@@ -234,7 +236,7 @@ __device__ __forceinline__ void write_obs_rows_generic(float *__restrict__ dst,
                     const float hv = heads[el * head_stride + (s >= 0 ? s : 0)];
                     v = s >= 0 ? hv : v;
                 }
-                if (in) *at(base, (unsigned)(el * D + col)) = v;
+                if (in) *at(base, (unsigned)(el * P + col)) = v;
             }
         }
     }

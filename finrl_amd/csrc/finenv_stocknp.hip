@@ -47,6 +47,7 @@ struct NpParams {
     const uint8_t *mask;
     int32_t auto_reset;
     int32_t D;
+    int32_t obs_pitch;              // row pitch of obs in floats (>= D; D = packed rows)
     uint32_t magicN;
     unsigned long long *dbg;      // FINENV_DIAG builds only: [wave][16] s_memrealtime stamps
     int32_t diag;                 // FINENV_DIAG builds only: experiment switches (env FINENV_DIAG)
@@ -132,13 +133,14 @@ __device__ __forceinline__ void np_write_rows(float *__restrict__ dst, const NpP
                                               int lane, int k_lo = 0, int k_hi = 1 << 30)
 {
     const int N = p.cfg.n_tickers, D = p.D;
+    const int pitch = dst == p.obs ? p.obs_pitch : D;      // (terminal observations stay packed)
     write_obs_rows_generic<8, 16, kCompact>(
         dst, p.panel.obs_tmpl, D, e0, nenv_w, row_day, lane_mask, heads, kRowH, lane,
         [=](int day, int col) { return day * D + col; },
         [=](int col) {                                       // amount | ... | stocks | cool_down
             const int hidx = col - 3 - N;
             return col == 0 ? 0 : ((hidx >= 0 && hidx < 2 * N) ? 1 + hidx : -1);
-        }, k_lo, k_hi);
+        }, k_lo, k_hi, pitch);
 }
 
 // (stocks * price).sum() in float32, NumPy pairwise order (8 accumulators, n < 128)
@@ -289,7 +291,7 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
             head_plan(hp, ldshead, p.D, rd, __builtin_amdgcn_readfirstlane(rd), vm, lane, kpatch,
                       head_widx);
             if (hp.uniform)
-                head_store(hp, p.obs, p.D, p.D, e0, nenv_w, vm, lane, kWave / 2, kWave,
+                head_store(hp, p.obs, p.D, p.obs_pitch, e0, nenv_w, vm, lane, kWave / 2, kWave,
                            [heads](int el, int w) { return heads[el * kRowH + w]; });
             else
                 np_write_rows(p.obs, p, e0, nenv_w, rd, vm & 0xFFFFFFFF00000000ull, heads, lane, 0,
@@ -545,7 +547,7 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
         HeadPlan<kHeadMax> hp;
         head_plan(hp, ldshead, p.D, row_day, day0, valid_mask, lane, kpatch, head_widx);
         if (done_mask == 0ull && hp.uniform)
-            head_store(hp, p.obs, p.D, p.D, e0, nenv_w, valid_mask, lane, 0, kWave / 2,
+            head_store(hp, p.obs, p.D, p.obs_pitch, e0, nenv_w, valid_mask, lane, 0, kWave / 2,
                        [heads](int el, int w) { return heads[el * kRowH + w]; });
         else
             np_write_rows(p.obs, p, e0, nenv_w, row_day,
@@ -566,6 +568,7 @@ struct finenv_stocknp {
     finenv_stocknp_state st;
     int bound;
     int D;
+    int obs_pitch;        // row pitch of the obs buffers handed to step / reset (floats)
     uint32_t magicN;
     char err[256];
 };
@@ -593,6 +596,7 @@ NpParams np_params(const finenv_stocknp *h)
     p.panel = h->panel;
     p.st = h->st;
     p.D = h->D;
+    p.obs_pitch = h->obs_pitch;
     p.magicN = h->magicN;
     return p;
 }
@@ -624,6 +628,7 @@ int finenv_stocknp_create(const finenv_stocknp_config *cfg, finenv_stocknp **out
     h->device = -1;
     h->cfg = *cfg;
     h->D = (int)D;
+    h->obs_pitch = (int)D;
     h->magicN = N >= 2 ? (uint32_t)(((1ull << 32) + N - 1) / (unsigned long long)N) : 0u;
     *out = h;
     return FINENV_OK;
@@ -632,6 +637,16 @@ int finenv_stocknp_create(const finenv_stocknp_config *cfg, finenv_stocknp **out
 void finenv_stocknp_destroy(finenv_stocknp *h) { delete h; }
 const char *finenv_stocknp_last_error(const finenv_stocknp *h) { return h ? h->err : "null handle"; }
 int finenv_stocknp_obs_dim(const finenv_stocknp *h) { return h ? h->D : FINENV_ERR_INVALID; }
+
+int finenv_stocknp_set_obs_pitch(finenv_stocknp *h, int32_t pitch)
+{
+    if (!h) return FINENV_ERR_INVALID;
+    if (pitch == 0) pitch = h->D;
+    if (pitch < h->D || (long long)pitch * 64 * 4 > (1ll << 32) - 1)
+        return np_fail(h, FINENV_ERR_INVALID, "set_obs_pitch: pitch must be >= obs_dim");
+    h->obs_pitch = pitch;
+    return FINENV_OK;
+}
 
 int finenv_stocknp_bind(finenv_stocknp *h, const finenv_stocknp_panel *panel,
                         const finenv_stocknp_state *st)

@@ -4,6 +4,7 @@ one HIP launch per step through the C ABI (finenv_stocknp_*)."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -38,7 +39,7 @@ class VecStockTradingEnvNP:
     def __init__(self, config, num_envs, *, gamma=0.99, turbulence_thresh=99, min_stock_rate=0.1,
                  max_stock=1e2, initial_capital=1e6, buy_cost_pct=1e-3, sell_cost_pct=1e-3,
                  reward_scaling=2 ** -11, initial_stocks=None, auto_reset=True, device="cuda",
-                 seed=0, obs_amount_floor=0.0):
+                 seed=0, obs_amount_floor=0.0, obs_pitch=None):
         import torch
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -96,7 +97,17 @@ class VecStockTradingEnvNP:
                                   self._f32.data_ptr())
         nat.check(L.finenv_stocknp_bind(self._h, C.byref(pp), C.byref(sp)), self._h, "bind",
                   "stocknp")
-        self.obs = torch.zeros(E, D, dtype=torch.float32, device=dev)
+        # obs: [E, D] view of a buffer whose rows start on 64-byte boundaries (see
+        # VecStockTradingEnv: packed rows share 64-byte segments that are then written twice)
+        if obs_pitch is None:
+            obs_pitch = os.environ.get("FINENV_OBS_PITCH", "aligned")
+        pitch = (D + 15) // 16 * 16 if obs_pitch == "aligned" else (D if obs_pitch == "packed" else int(obs_pitch))
+        if pitch < D:
+            raise ValueError("obs_pitch must be >= the observation dimension")
+        self._obs_buf = torch.zeros(E, pitch, dtype=torch.float32, device=dev)
+        self.obs = self._obs_buf[:, :D]
+        self._pitch = self._pitch_set = pitch
+        nat.check(L.finenv_stocknp_set_obs_pitch(self._h, pitch), self._h, "set_obs_pitch", "stocknp")
         self.reward = torch.zeros(E, dtype=torch.float32, device=dev)
         self.done = torch.zeros(E, dtype=torch.uint8, device=dev)
         self.term_obs = None
@@ -141,8 +152,15 @@ class VecStockTradingEnvNP:
     def enable_terminal_obs(self):
         import torch
         if self.term_obs is None:
-            self.term_obs = torch.zeros_like(self.obs)
+            self.term_obs = torch.zeros(self.num_envs, self.obs.shape[1], dtype=torch.float32,
+                                        device=self.device)
         return self.term_obs
+
+    def _use_pitch(self, pitch):
+        if pitch != self._pitch_set:
+            nat.check(nat.lib().finenv_stocknp_set_obs_pitch(self._h, int(pitch)), self._h,
+                      "set_obs_pitch", "stocknp")
+            self._pitch_set = pitch
 
     def reset(self, mask=None):
         import torch
@@ -152,6 +170,7 @@ class VecStockTradingEnvNP:
         if mask is not None:
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
             mptr = C.c_void_p(mask.data_ptr())
+        self._use_pitch(self._pitch)
         nat.check(nat.lib().finenv_stocknp_reset(self._h, mptr, C.c_void_p(self.obs.data_ptr()),
                                                  self._stream()), self._h, "reset", "stocknp")
         return self.obs
@@ -162,6 +181,9 @@ class VecStockTradingEnvNP:
                 actions.device != self.obs.device:
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
         obs, rew, done = out if out is not None else (self.obs, self.reward, self.done)
+        if obs.stride(-1) != 1 or tuple(obs.shape) != tuple(self.obs.shape):
+            raise ValueError("out[0] must be [E, D] float32 with unit column stride")
+        self._use_pitch(obs.stride(0))
         nat.check(nat.lib().finenv_stocknp_step(
             self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(obs.data_ptr()),
             C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()),

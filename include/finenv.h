@@ -374,6 +374,8 @@ int  finenv_stocknp_create(const finenv_stocknp_config *cfg, finenv_stocknp **ou
 void finenv_stocknp_destroy(finenv_stocknp *h);
 const char *finenv_stocknp_last_error(const finenv_stocknp *h);
 int  finenv_stocknp_obs_dim(const finenv_stocknp *h);
+/* row pitch (floats) of the obs buffers of step / reset; see finenv_stock_set_obs_pitch */
+int  finenv_stocknp_set_obs_pitch(finenv_stocknp *h, int32_t pitch);
 int  finenv_stocknp_bind(finenv_stocknp *h, const finenv_stocknp_panel *panel,
                          const finenv_stocknp_state *state);
 /* reset() (:80-101) from the per-env start state (stocks0, amount0, amount0_tag): eval mode =
