@@ -16,7 +16,7 @@ for ENV in portfolio crypto stocknp cashpenalty stoploss; do
 import csv, glob, json, os, sys
 out, env = sys.argv[1], sys.argv[2]
 needle = {"portfolio": "portfolio_step_kernel", "crypto": "crypto_kernel<false", "stocknp": "stocknp_kernel<false>",
-          "cashpenalty": "cashpenalty_kernel<false", "stoploss": "stoploss_kernel<false"}[env]
+          "cashpenalty": "cashpenalty_kernel<false", "stoploss": "stoploss_step"}[env]
 def med(ctr):
     f = glob.glob(os.path.join(out, f"{env}_{ctr}", "**", "*counter_collection.csv"), recursive=True)
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f[0]))

@@ -17,6 +17,8 @@ python3 tools/phase_times.py 65536 100 2>&1 | grep -v amdgpu.ids > $ROOT/gpurun_
 python3 tools/phase_times_crypto.py 32768 2>&1 | grep -v amdgpu.ids > $ROOT/gpurun_out/r02/f_phase_crypto.txt
 python3 tools/phase_times_stocknp.py 2>&1 | grep -v amdgpu.ids > $ROOT/gpurun_out/r02/f_phase_stocknp.txt
 python3 tools/phase_times_cashpenalty.py 2>&1 | grep -v amdgpu.ids > $ROOT/gpurun_out/r02/f_phase_cashpenalty.txt
+python3 tools/phase_times_stoploss.py 2>&1 | grep -v amdgpu.ids > $ROOT/gpurun_out/r02/f_phase_stoploss.txt
+python3 tools/phase_times.py 65536 30 desync 2>&1 | grep -v amdgpu.ids > $ROOT/gpurun_out/r02/f_phase_n30_desync.txt
 python3 -c "import __graft_entry__ as g; g.smoke()" > $ROOT/gpurun_out/r02/f_smoke.txt 2>&1
 python3 bench.py > $ROOT/gpurun_out/r02/f_default_bench.json 2> $ROOT/gpurun_out/r02/f_default_bench.err
 tail -c 600 $ROOT/gpurun_out/r02/f_default_bench.json
