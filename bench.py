@@ -272,6 +272,7 @@ def build_workload(args, torch, dev, rank):
                 w.env.state["day"].copy_(offs)
                 w.env.state["price_day"].copy_(offs)
                 w.env.state["start_day"].copy_(offs)
+                w.env.hint_desynchronised(True)
             w.after_reset = _desync
     elif args.env == "portfolio":
         from finrl_amd.panel import PortfolioPanel

@@ -179,6 +179,7 @@ def lib():
     L.finenv_stock_last_error.restype = C.c_char_p
     L.finenv_stock_obs_dim.argtypes = [C.c_void_p]
     L.finenv_stock_set_obs_pitch.argtypes = [C.c_void_p, C.c_int32]
+    L.finenv_stock_set_desync_hint.argtypes = [C.c_void_p, C.c_int32]
     L.finenv_stock_bind.argtypes = [C.c_void_p, C.POINTER(StockPanelPtrs),
                                     C.POINTER(StockStatePtrs)]
     L.finenv_stock_init.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]

@@ -68,6 +68,7 @@ struct finenv_stock {
     int bound;
     int D;
     int obs_pitch;        // row pitch of the obs buffers handed to step / reset / observe (floats)
+    int desync_hint;      // finenv_stock_set_desync_hint
     uint32_t magicN;
     char err[256];
 };
@@ -99,6 +100,7 @@ Params make_params(const finenv_stock *h)
     p.st = h->st;
     p.D = h->D;
     p.obs_pitch = h->obs_pitch;
+    p.desync_hint = h->desync_hint;
     p.magicN = h->magicN;
     return p;
 }
@@ -217,6 +219,13 @@ void finenv_stock_destroy(finenv_stock *h) { delete h; }
 const char *finenv_stock_last_error(const finenv_stock *h) { return h ? h->err : "null handle"; }
 
 int finenv_stock_obs_dim(const finenv_stock *h) { return h ? h->D : FINENV_ERR_INVALID; }
+
+int finenv_stock_set_desync_hint(finenv_stock *h, int32_t on)
+{
+    if (!h) return FINENV_ERR_INVALID;
+    h->desync_hint = on != 0;
+    return FINENV_OK;
+}
 
 int finenv_stock_set_obs_pitch(finenv_stock *h, int32_t pitch)
 {

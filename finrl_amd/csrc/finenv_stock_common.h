@@ -32,6 +32,7 @@ struct Params {
     int32_t auto_reset;
     int32_t D;
     int32_t obs_pitch;    // row pitch of `obs` in floats (>= D; D = packed rows)
+    int32_t desync_hint;  // envs may sit on different days (selects the kernel instantiation only)
     int32_t day0;
     uint32_t magicN;      // ceil(2^32 / N) for N >= 2 (exact f / N for f < 2^16)
     int32_t diag;         // FINENV_DIAG builds only: phase-skip bitmask (timing experiments)

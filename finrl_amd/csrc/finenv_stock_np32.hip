@@ -20,7 +20,10 @@ int launch_step(const Params &p, int device, hipStream_t stream)
     const dim3 grid((unsigned)((p.cfg.n_envs + kWave - 1) / kWave)), block(kStepThreads);
     constexpr size_t lds = sizeof(float) * np32::kLdsStep;
     (void)device;
-    hipLaunchKernelGGL((np32::stock_step_kernel<TURB, STATS>), grid, block, lds, stream, p);
+    if (p.desync_hint)      // envs may sit on different days: the instantiation with the per-env fast paths
+        hipLaunchKernelGGL((np32::stock_step_kernel<TURB, STATS, true>), grid, block, lds, stream, p);
+    else
+        hipLaunchKernelGGL((np32::stock_step_kernel<TURB, STATS, false>), grid, block, lds, stream, p);
     return 0;
 }
 }  // namespace

@@ -147,6 +147,13 @@ class VecStockTradingEnv:
                                         device=self.device)
         return self.term_obs
 
+    def hint_desynchronised(self, on=True):
+        """Performance hint (results never depend on it): the envs of this batch sit on different
+        days -- per-env start days, staggered episode ends.  Selects the step-kernel instantiation
+        tuned for per-env panel rows (finenv_stock_set_desync_hint)."""
+        nat.check(nat.lib().finenv_stock_set_desync_hint(self._h, int(bool(on))), self._h,
+                  "set_desync_hint")
+
     def _use_pitch(self, pitch):
         if pitch != self._pitch_set:
             nat.check(nat.lib().finenv_stock_set_obs_pitch(self._h, int(pitch)), self._h,

@@ -157,6 +157,13 @@ int  finenv_stock_obs_dim(const finenv_stock *h);
  * stored).  The consumer sees a [E][D] view with a row stride. */
 int  finenv_stock_set_obs_pitch(finenv_stock *h, int32_t pitch);
 
+/* Performance hint, never needed for correctness: the envs of this batch may sit on different days
+ * (per-env start days, episodes that end at different steps).  step() then launches the kernel
+ * instantiation whose per-env panel-row paths are tuned (16-byte row copies, row-wise price gather,
+ * parked head chunks); with every env on the same day -- the reference's training setup, BASELINE's
+ * configs -- leave it off: that instantiation carries none of that code. */
+int  finenv_stock_set_desync_hint(finenv_stock *h, int32_t on);
+
 /* Attach the panel and state buffers (replaces self.df / self.state ownership). */
 int finenv_stock_bind(finenv_stock *h, const finenv_stock_panel *panel,
                       const finenv_stock_state *state);

@@ -169,11 +169,13 @@ def test_hip_matches_oracle_random_batch(cfg):
     assert n_done >= 2
 
 
-@pytest.mark.parametrize("N,K", [(30, 8), (100, 3), (50, 2)])
-def test_hip_desynchronised_envs(N, K):
+@pytest.mark.parametrize("N,K,hint", [(30, 8, True), (30, 8, False), (7, 3, True), (100, 3, True),
+                                      (50, 2, True), (50, 2, False)])
+def test_hip_desynchronised_envs(N, K, hint):
     """Envs that are NOT in lock-step (different days inside one wave, via masked resets):
     exercises the per-row reload path of the observation writer and per-lane price gathers, in
-    every kernel variant (32-wide, the N = 100 one, 64-wide)."""
+    every kernel variant (32-wide, the N = 100 one, 64-wide), with and without the
+    desynchronised-batch hint (two instantiations of the 32-wide kernel, same results)."""
     _need_gpu()
     from finrl_amd import StockPanel
     from oracle.stock import StockOracle, lib, _p
@@ -183,6 +185,7 @@ def test_hip_desynchronised_envs(N, K):
     kw = dict(hmax=100, initial_amount=300_000, turbulence_threshold=50.0)
     orc = StockOracle(close, tech, risk, n_envs=E, **kw)
     env = _make_env(StockPanel(close, tech, risk), E, auto_reset=True, **kw)
+    env.hint_desynchronised(hint)
     orc.reset()
     env.reset()
     for s in range(80):

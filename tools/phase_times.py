@@ -28,6 +28,7 @@ def main():
         offs = torch.randint(0, close.shape[0] - 1, (E,), device="cuda").to(torch.int32)
         for k in ("day", "price_day", "start_day"):
             env.state[k].copy_(offs)
+        env.hint_desynchronised(True)
     nb = (E + 63) // 64
     buf = torch.zeros(nb * 2 * 16, dtype=torch.int64, device="cuda")
     pool = [torch.rand(E, NT, device="cuda") * 2 - 1 for _ in range(8)]
