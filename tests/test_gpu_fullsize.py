@@ -175,3 +175,50 @@ def test_fullsize_two_full_episodes_sampled_oracle():
     np.testing.assert_array_equal(st["holdings"].T[idx].cpu().numpy(), os_["shares"])
     np.testing.assert_array_equal(st["trades"][idx].cpu().numpy(), os_["trades"])
     assert bool((st["episode"] == 3).all())
+
+
+@pytest.mark.parametrize("hint", [True, False])
+def test_fullsize_desynchronised_sampled_oracle(hint):
+    """65,536 envs driven out of lock step by masked resets (different days inside every wave,
+    episode ends at different steps), with and without the desynchronised-batch hint -- the two
+    instantiations of the step kernel -- exact against the oracle on a sampled subset."""
+    import ctypes as C
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device visible: GPU tests must run on the MI355X box")
+    from finrl_amd import StockPanel
+    from finrl_amd.vec_env import VecStockTradingEnv
+    from oracle.stock import StockOracle, lib, _p
+    T, N, K = 24, 30, 8
+    rng = np.random.default_rng(21)
+    close = 100 * np.exp(np.cumsum(rng.normal(0, 0.01, (T, N)), axis=0))
+    tech = rng.normal(0, 1, (T, K, N))
+    tech[:, 0, :][rng.random((T, N)) < 0.03] = 1.0
+    risk = np.abs(rng.normal(0, 30, T))
+    kw = dict(hmax=100, initial_amount=300_000, turbulence_threshold=50.0)
+    sample = np.unique(np.concatenate([[0, 63, 64, 127, 128, E - 1], rng.choice(E, 200, replace=False)]))
+    env = VecStockTradingEnv(StockPanel(close, tech, risk), E, auto_reset=True, **kw)
+    env.hint_desynchronised(hint)
+    orc = StockOracle(close, tech, risk, n_envs=len(sample), **kw)
+    orc.reset()
+    env.reset()
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(4)
+    for s in range(70):
+        a = torch.rand(E, N, generator=gen, device="cuda") * 2 - 1
+        o_obs, o_rew, o_done, _ = orc.vec_step(a[sample].cpu().numpy())
+        obs, rew, done, _ = env.step(a)
+        np.testing.assert_array_equal(obs[sample].cpu().numpy(), o_obs.astype(np.float32), err_msg=f"{s}")
+        np.testing.assert_array_equal(rew[sample].cpu().numpy(), o_rew.astype(np.float32))
+        np.testing.assert_array_equal(done[sample].cpu().numpy().astype(bool), o_done)
+        if s in (2, 5, 9, 14):
+            m = rng.random(E) < 0.3
+            for j, e in enumerate(sample):
+                if m[e]:
+                    row = np.empty(orc.D)
+                    lib().stock_oracle_reset_env(orc._h, C.c_int(int(j)), _p(row))
+            env.reset(torch.from_numpy(m.astype(np.uint8)).cuda())
+    st, os_ = env.state_numpy(), orc.state()
+    assert len(np.unique(st["day"])) > 4
+    np.testing.assert_array_equal(st["day"][sample], os_["day"])
+    np.testing.assert_array_equal(st["cash"][sample], os_["cash"])
+    np.testing.assert_array_equal(st["shares"][sample], os_["shares"])

@@ -158,3 +158,53 @@ def test_config4_crypto_shard_with_rollout_buffers():
                                      last_v[sample].cpu().numpy(), 0.99, 0.95)
     np.testing.assert_allclose(adv[:, sample].cpu().numpy(), ref_adv, rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(ret[:, sample].cpu().numpy(), ref_ret, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("kind", ["cashpenalty", "stoploss"])
+def test_cashpenalty_stoploss_fullsize_sampled_oracle(kind):
+    """65,536 cash-penalty / stop-loss envs on per-env dates (pinned random starting points): the
+    two-wave kernels with every block of the grid resident at once (LDS flag hand-off, speculated
+    rows, auto-resets at different steps), exact against the oracle on a sampled subset."""
+    _need_gpu()
+    from finrl_amd.vec_cashpenalty import CashPenaltyPanel, VecCashPenaltyEnv, VecStopLossEnv
+    from oracle.cashpenalty import CashPenaltyOracle
+    from oracle.stoploss import StopLossOracle
+    E, T, N, Cc = 65_536, 48, 30, 5
+    rng = np.random.default_rng(11)
+    close = 50 * np.exp(np.cumsum(rng.normal(0, 0.01, (T, N)), axis=0))
+    info = rng.normal(0, 10, (T, N, Cc))
+    turb = np.abs(rng.normal(0, 30, T))
+    kw = dict(hmax=30_000, turbulence_threshold=70.0, patient=False, initial_amount=5e5,
+              buy_cost_pct=0.002, sell_cost_pct=0.001, cash_penalty_proportion=0.15)
+    cls, ocls = (VecCashPenaltyEnv, CashPenaltyOracle) if kind == "cashpenalty" else \
+        (VecStopLossEnv, StopLossOracle)
+    sample = _sample(E)
+    env = cls(CashPenaltyPanel(close, info, turb), E, random_start=False, **kw)
+    orc = ocls(close, info, turb, n_envs=len(sample), **kw)
+    env.enable_terminal_obs()
+    starts = rng.integers(0, T // 2, E).astype(np.int32)
+    env.set_next_start(starts)
+    np.testing.assert_array_equal(env.reset()[sample].cpu().numpy(),
+                                  orc.reset(starts[sample]).astype(np.float32))
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    n_done = 0
+    for s in range(60):
+        a = torch.rand(E, N, generator=gen, device="cuda") * 2 - 1
+        starts = rng.integers(0, T // 2, E).astype(np.int32)
+        env.set_next_start(starts)
+        o_obs, o_rew, o_done, o_term = orc.vec_step(a[sample].cpu().numpy(), starts[sample])
+        obs, rew, done, _ = env.step(a)
+        np.testing.assert_array_equal(done[sample].cpu().numpy().astype(bool), o_done, err_msg=f"{s}")
+        np.testing.assert_array_equal(obs[sample].cpu().numpy(), o_obs.astype(np.float32))
+        np.testing.assert_array_equal(rew[sample].cpu().numpy(), o_rew.astype(np.float32))
+        if o_done.any():
+            np.testing.assert_array_equal(env.term_obs[sample].cpu().numpy()[o_done],
+                                          o_term[o_done].astype(np.float32))
+        n_done += int(done.sum())
+        # every observation row is complete: cash column finite, no row left at the buffer's zeros
+        assert bool(torch.isfinite(obs).all()) and float(obs[:, 0].min()) > 0
+    st, os_ = env.state_numpy(), orc.state()
+    for k in ("coh", "holdings", "date_index", "start", "episode"):
+        np.testing.assert_array_equal(st[k][sample], os_[k], err_msg=k)
+    assert n_done > E                                   # more than one episode end per env on average
