@@ -349,7 +349,8 @@ def attach_rollout(w, args, torch, dev, gen):
     """BASELINE configs[4]: PPO rollout collection into device-resident [n_steps, E, .] buffers.
     Every step writes obs / reward / done straight into slice t (the C ABI takes output pointers:
     no staging copy), actions / values / log-probs of a stand-in policy (random tensors: no network is part of
-    the env path) are stored by one launch (finenv_rollout_put), and every n_steps steps the GAE scan kernel runs
+    the env path) are stored by the env step's own launch where the env supports it (finenv_crypto_step_record:
+    extra blocks beside the env blocks), else by one launch of their own (finenv_rollout_put), and every n_steps steps the GAE scan kernel runs
     (finenv_gae_scan).  Still one env step per `step`."""
     from finrl_amd.rollout import RolloutBuffer
     n = int(args.rollout)
@@ -372,8 +373,7 @@ def attach_rollout(w, args, torch, dev, gen):
     state = dict(t=0)
 
     def one(t, i):
-        buf.put(t, w.pool[i % len(w.pool)], vals[i & 3], lps[i & 3])
-        env.step(buf.actions[t], out=(buf.obs[t + 1], buf.rewards[t], buf.dones[t]))
+        buf.step(env, t, w.pool[i % len(w.pool)], vals[i & 3], lps[i & 3])
 
     def finish(i):
         buf.compute_returns_and_advantage(vals[i & 3], gamma=0.99, gae_lambda=0.95)
@@ -388,9 +388,9 @@ def attach_rollout(w, args, torch, dev, gen):
                 finish(i)
                 t = 0
             state["t"] = t
-        w.config_extra["launch"] = "eager (2 launches per step)"
+        w.config_extra["launch"] = "eager"
     else:
-        # a whole segment -- n x (policy-output store + env step) + GAE scan + carry-over copy -- is ONE
+        # a whole segment -- n x (env step that also records the policy's outputs) + GAE scan + carry-over copy -- is ONE
         # hipGraph: replayed with one host call per n steps (every step() of the envs is a plain
         # launch on the caller's stream: no allocation, sync or host read-back in the C ABI)
         cur = torch.cuda.current_stream(dev)

@@ -211,6 +211,7 @@ def lib():
     L.finenv_crypto_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.finenv_crypto_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int32, C.c_void_p]
+    L.finenv_crypto_step_record.argtypes = [C.c_void_p] * 6 + [C.c_int32] + [C.c_void_p] * 6
     L.finenv_stocknp_create.argtypes = [C.POINTER(StockNpConfig), C.POINTER(C.c_void_p)]
     L.finenv_stocknp_destroy.argtypes = [C.c_void_p]
     L.finenv_stocknp_destroy.restype = None

@@ -60,6 +60,12 @@ struct CrParams {
     int32_t D;
     uint32_t magicN;
     uint32_t magicW;
+    // finenv_crypto_step_record: blocks >= env_blocks copy the policy's outputs of this step into
+    // the rollout tensors (16-byte elements), beside the env blocks
+    int32_t env_blocks;
+    int32_t rec_na4, rec_nv4;     // float4 counts: actions [E*N/4], values / log-probs [E/4]
+    const float *rec_src[3];      // actions (== actions), values, log-probs
+    float *rec_dst[3];
     unsigned long long *dbg;      // FINENV_DIAG builds only: [wave][16] s_memrealtime stamps
 };
 
@@ -121,6 +127,22 @@ template <bool RESET_ONLY, int kWaves, int NP>
 __global__ void __launch_bounds__(kWave *kWaves, 1) crypto_kernel(const CrParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];   // kWaves * lds_per_wave(D)
+    if (!RESET_ONLY && p.env_blocks > 0 && (int)blockIdx.x >= p.env_blocks) {
+        // ---- record blocks (finenv_crypto_step_record): the step's policy outputs -> slice t of
+        // the rollout tensors.  At 32,768 envs the env blocks occupy half the SIMDs of the chip and
+        // the step is a chain of dependent round trips: the copy rides along for free instead of
+        // costing a launch of its own (2-3 us with its launch gap, of a 10 us step).
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const int nthreads = ((int)gridDim.x - p.env_blocks) * (int)blockDim.x;
+        const int tid = ((int)blockIdx.x - p.env_blocks) * (int)blockDim.x + (int)threadIdx.x;
+        const int na4 = p.rec_na4, nv4 = p.rec_nv4;
+        for (int i = tid; i < na4 + 2 * nv4; i += nthreads) {
+            const int k = i < na4 ? 0 : (i < na4 + nv4 ? 1 : 2);
+            const int j = i - (k == 0 ? 0 : (k == 1 ? na4 : na4 + nv4));
+            reinterpret_cast<f4 *>(p.rec_dst[k])[j] = reinterpret_cast<const f4 *>(p.rec_src[k])[j];
+        }
+        return;
+    }
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = threadIdx.x >> 6;
     float *rows = lds_all + wib * lds_per_wave(p.D);        // [env][kRow]: actions, then obs heads
@@ -423,12 +445,20 @@ template <bool RESET_ONLY, int NP>
 void cr_launch_np(const CrParams &p, hipStream_t stream)
 {
     const int waves = (p.cfg.n_envs + kWave - 1) / kWave;
-    if (waves <= kSmallWaves)
-        hipLaunchKernelGGL((crypto_kernel<RESET_ONLY, 1, NP>), dim3((unsigned)waves), dim3(kWave),
-                           sizeof(float) * lds_per_wave(p.D), stream, p);
-    else
-        hipLaunchKernelGGL((crypto_kernel<RESET_ONLY, 4, NP>), dim3((unsigned)((waves + 3) / 4)),
-                           dim3(kWave * 4), sizeof(float) * 4 * lds_per_wave(p.D), stream, p);
+    CrParams q = p;
+    const int n4 = p.rec_na4 + 2 * p.rec_nv4;            // record work (0: plain step)
+    if (waves <= kSmallWaves) {
+        const int rec_blocks = n4 > 0 ? min(512, (n4 + kWave * 8 - 1) / (kWave * 8)) : 0;
+        q.env_blocks = n4 > 0 ? waves : 0;
+        hipLaunchKernelGGL((crypto_kernel<RESET_ONLY, 1, NP>), dim3((unsigned)(waves + rec_blocks)),
+                           dim3(kWave), sizeof(float) * lds_per_wave(p.D), stream, q);
+    } else {
+        const int blocks = (waves + 3) / 4;
+        const int rec_blocks = n4 > 0 ? min(256, (n4 + kWave * 32 - 1) / (kWave * 32)) : 0;
+        q.env_blocks = n4 > 0 ? blocks : 0;
+        hipLaunchKernelGGL((crypto_kernel<RESET_ONLY, 4, NP>), dim3((unsigned)(blocks + rec_blocks)),
+                           dim3(kWave * 4), sizeof(float) * 4 * lds_per_wave(p.D), stream, q);
+    }
 }
 template <bool RESET_ONLY>
 void cr_launch(const CrParams &p, hipStream_t stream)
@@ -515,6 +545,43 @@ int finenv_crypto_step(finenv_crypto *h, const float *actions, float *obs, float
 #endif
     cr_launch<false>(p, (hipStream_t)stream);
     return cr_check(h, "crypto_step");
+}
+
+int finenv_crypto_step_record(finenv_crypto *h, const float *actions, float *obs, float *reward,
+                              uint8_t *done, float *term_obs, int32_t auto_reset,
+                              const float *values, const float *log_probs, float *actions_out,
+                              float *values_out, float *log_probs_out, void *stream)
+{
+    if (!h) return FINENV_ERR_INVALID;
+    if (!h->bound) return cr_fail(h, FINENV_ERR_UNBOUND, "step_record: bind first");
+    const finenv_host::DeviceGuard guard(h->device);
+    if (!actions || !obs || !reward || !done || !values || !log_probs || !actions_out ||
+        !values_out || !log_probs_out)
+        return cr_fail(h, FINENV_ERR_INVALID, "step_record: null pointer");
+    const long long na = (long long)h->cfg.n_envs * h->cfg.n_assets, nv = h->cfg.n_envs;
+    const uintptr_t bits = (uintptr_t)actions | (uintptr_t)values | (uintptr_t)log_probs |
+                           (uintptr_t)actions_out | (uintptr_t)values_out | (uintptr_t)log_probs_out;
+    if ((bits & 15) != 0 || (na & 3) != 0 || (nv & 3) != 0)
+        return cr_fail(h, FINENV_ERR_INVALID,
+                       "step_record: 16-byte aligned buffers and n_envs % 4 == 0 required "
+                       "(use finenv_crypto_step + finenv_rollout_put otherwise)");
+    CrParams p = cr_params(h);
+    p.actions = actions;
+    p.obs = obs;
+    p.reward = reward;
+    p.done = done;
+    p.term_obs = term_obs;
+    p.auto_reset = auto_reset;
+    p.rec_na4 = (int32_t)(na / 4);
+    p.rec_nv4 = (int32_t)(nv / 4);
+    p.rec_src[0] = actions;      p.rec_dst[0] = actions_out;
+    p.rec_src[1] = values;       p.rec_dst[1] = values_out;
+    p.rec_src[2] = log_probs;    p.rec_dst[2] = log_probs_out;
+#ifdef FINENV_DIAG
+    p.dbg = g_finenv_dbg;
+#endif
+    cr_launch<false>(p, (hipStream_t)stream);
+    return cr_check(h, "crypto_step_record");
 }
 
 }  // extern "C"

@@ -55,10 +55,7 @@ class GraphedSegment:
         buf, env = self.buf, self.env
         for t in range(buf.n_steps):
             a, v, lp = policy(buf.obs[t])
-            buf.actions[t].copy_(a)
-            buf.values[t].copy_(v)
-            buf.log_probs[t].copy_(lp)
-            env.step(buf.actions[t], out=(buf.obs[t + 1], buf.rewards[t], buf.dones[t]))
+            buf.step(env, t, a, v, lp)
 
     def replay(self, first_obs=None):
         if first_obs is not None:

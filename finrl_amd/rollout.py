@@ -43,13 +43,28 @@ class RolloutBuffer:
             C.c_void_p(self.log_probs[t].data_ptr()), self.num_envs,
             self.actions.shape[2], stream), None, "finenv_rollout_put")
 
+    def step(self, env, t, actions, values, log_probs):
+        """Store the policy's outputs of step t and step the env into slice t: one launch where the
+        env can record them itself (`supports_record`: finenv_crypto_step_record), else two."""
+        import torch
+        out = (self.obs[t + 1], self.rewards[t], self.dones[t])
+        fused = getattr(env, "supports_record", False) and self.num_envs % 4 == 0 and \
+            (self.num_envs * self.actions.shape[2]) % 4 == 0 and \
+            all(x.dtype == torch.float32 and x.is_contiguous() and x.data_ptr() % 16 == 0
+                for x in (actions, values, log_probs))
+        if fused:
+            env.step(actions, out=out, record=(values, log_probs, self.actions[t], self.values[t],
+                                               self.log_probs[t]))
+        else:
+            self.put(t, actions, values, log_probs)
+            env.step(self.actions[t], out=out)
+
     def collect(self, env, policy, first_obs):
         """policy(obs) -> (actions [E,A] f32, values [E], log_probs [E]) on device."""
         self.obs[0].copy_(first_obs)
         for t in range(self.n_steps):
             a, v, lp = policy(self.obs[t])
-            self.put(t, a, v, lp)
-            env.step(self.actions[t], out=(self.obs[t + 1], self.rewards[t], self.dones[t]))
+            self.step(env, t, a, v, lp)
         return self.obs[self.n_steps]
 
     def compute_returns_and_advantage(self, last_values, gamma=0.99, gae_lambda=0.95):

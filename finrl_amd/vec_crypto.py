@@ -113,15 +113,37 @@ class VecCryptoEnv:
                                                 self._stream()), self._h, "reset", "crypto")
         return self.obs
 
-    def step(self, actions, out=None):
+    supports_record = True      # step(..., record=...) stores the policy's outputs in the same launch
+
+    def step(self, actions, out=None, record=None):
         """actions f32 [E,N] (NOT modified: the reference scales its input in place, :63-65).
         out=(obs, reward, done) optionally directs the outputs into caller tensors, e.g. slice t
-        of rollout buffers [n_steps, E, ...] -- collecting a rollout needs no copy."""
+        of rollout buffers [n_steps, E, ...] -- collecting a rollout needs no copy.
+        record=(values, log_probs, actions_out, values_out, log_probs_out): also copy this step's
+        policy outputs into the rollout tensors, in the same launch (finenv_crypto_step_record;
+        contiguous float32, 16-byte aligned, E % 4 == 0 -- else use RolloutBuffer.put)."""
         import torch
         if actions.dtype != torch.float32 or not actions.is_contiguous() or \
                 actions.device != self.obs.device:
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
         obs, rew, done = out if out is not None else (self.obs, self.reward, self.done)
+        if record is not None:
+            v, lp, a_out, v_out, lp_out = record
+            for t_ in (v, lp, a_out, v_out, lp_out):
+                if t_.dtype != torch.float32 or not t_.is_contiguous() or t_.device != self.obs.device:
+                    raise ValueError("record tensors must be contiguous float32 on the env's device")
+            if a_out.numel() != actions.numel() or v.numel() != self.num_envs or \
+                    lp.numel() != self.num_envs or v_out.numel() != self.num_envs or \
+                    lp_out.numel() != self.num_envs:
+                raise ValueError("record: expected values / log_probs [E] and actions_out [E, N]")
+            nat.check(nat.lib().finenv_crypto_step_record(
+                self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(obs.data_ptr()),
+                C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()),
+                C.c_void_p(self.term_obs.data_ptr()) if self.term_obs is not None else None,
+                int(self.auto_reset), C.c_void_p(v.data_ptr()), C.c_void_p(lp.data_ptr()),
+                C.c_void_p(a_out.data_ptr()), C.c_void_p(v_out.data_ptr()),
+                C.c_void_p(lp_out.data_ptr()), self._stream()), self._h, "step_record", "crypto")
+            return obs, rew, done, None
         nat.check(nat.lib().finenv_crypto_step(
             self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(obs.data_ptr()),
             C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()),

@@ -303,6 +303,15 @@ int  finenv_crypto_reset(finenv_crypto *h, const uint8_t *mask, float *obs_out, 
  * [n_steps][E][...]: collecting a rollout needs no extra copy. */
 int  finenv_crypto_step(finenv_crypto *h, const float *actions, float *obs, float *reward,
                         uint8_t *done, float *term_obs, int32_t auto_reset, void *stream);
+/* step() that also records the policy's outputs of this step into the rollout tensors, in the same
+ * launch (extra blocks beside the env blocks): actions -> actions_out [E][N], values -> values_out
+ * [E], log_probs -> log_probs_out [E] (what SB3's RolloutBuffer.add copies; obs / reward / done are
+ * written in place by the step itself).  All six buffers 16-byte aligned, E % 4 == 0, else
+ * FINENV_ERR_INVALID (use finenv_crypto_step + finenv_rollout_put). */
+int  finenv_crypto_step_record(finenv_crypto *h, const float *actions, float *obs, float *reward,
+                               uint8_t *done, float *term_obs, int32_t auto_reset,
+                               const float *values, const float *log_probs, float *actions_out,
+                               float *values_out, float *log_probs_out, void *stream);
 
 /* =====================================================================================
  * Rollout helper (caller side of the path): generalized advantage estimation

@@ -182,3 +182,37 @@ def test_rollout_put_odd_sizes():
     with pytest.raises(ValueError):
         buf.put(0, torch.zeros(E, A + 1, device="cuda"), torch.zeros(E, device="cuda"),
                 torch.zeros(E, device="cuda"))
+
+
+def test_crypto_step_record_matches_put_plus_step():
+    """finenv_crypto_step_record: the policy's outputs land in the rollout tensors and the step's
+    results are those of the plain step (two envs side by side); odd sizes fall back to two launches."""
+    _need_gpu()
+    from finrl_amd.rollout import RolloutBuffer
+    from finrl_amd.vec_crypto import VecCryptoEnv
+    rng = np.random.default_rng(8)
+    T, N, W = 30, 10, 40
+    price = 100 * np.exp(np.cumsum(rng.normal(0, 0.004, (T, N)), axis=0))
+    tech = rng.normal(0, 3000, (T, W))
+    for E in (1024, 300, 301):           # 301: E % 4 != 0 -> RolloutBuffer.step takes the two-launch path
+        a_env = VecCryptoEnv({"price_array": price, "tech_array": tech}, E)
+        b_env = VecCryptoEnv({"price_array": price, "tech_array": tech}, E)
+        buf = RolloutBuffer(6, E, a_env.obs_dim, N)
+        a_env.reset()
+        b_env.reset()
+        for t in range(6):
+            a = torch.rand(E, N, device="cuda") * 2 - 1
+            v, lp = torch.randn(E, device="cuda"), torch.randn(E, device="cuda")
+            buf.step(a_env, t, a, v, lp)
+            obs, rew, done, _ = b_env.step(a)
+            assert torch.equal(buf.actions[t], a) and torch.equal(buf.values[t], v)
+            assert torch.equal(buf.log_probs[t], lp)
+            assert torch.equal(buf.obs[t + 1], obs) and torch.equal(buf.rewards[t], rew)
+            assert torch.equal(buf.dones[t], done)
+    big = VecCryptoEnv({"price_array": price, "tech_array": tech}, 140_000)   # four-wave blocks
+    buf = RolloutBuffer(2, 140_000, big.obs_dim, N)
+    big.reset()
+    a = torch.rand(140_000, N, device="cuda") * 2 - 1
+    v, lp = torch.randn(140_000, device="cuda"), torch.randn(140_000, device="cuda")
+    buf.step(big, 0, a, v, lp)
+    assert torch.equal(buf.actions[0], a) and torch.equal(buf.values[0], v) and torch.equal(buf.log_probs[0], lp)
