@@ -220,7 +220,7 @@ cashpenalty_kernel(const CpParams p)
 
     if (role != 0) {
         // ---- streamer ---------------------------------------------------------------------------
-        if (NCH == 0) return;                 // rows wider than 192 columns: the trader writes them
+        if (NCH == 0) return;                 // rows wider than 320 columns: the trader writes them
         KSTAMP(8);
         const int W = p.D - 1 - N;
         const int di_s = KI(FINENV_KI_DATE_INDEX);
@@ -235,29 +235,36 @@ cashpenalty_kernel(const CpParams p)
         lds_barrier();                        // staging barrier: the trader reads its close rows
         const unsigned long long valid_mask = __ballot(valid);
         float *const base = p.obs + (size_t)e0 * p.D;
+        // market-data columns [64, D) of every row (NCH == 2: 64 < D <= 320): ONE 16-byte-per-lane load
+        // and store per row at 4-byte aligned addresses, the last quad shifted back to end at D (a
+        // wave's 64 vector-memory slots retire in order, ~47 ns each: the dword form -- up to four
+        // loads and four stores per row -- covered rows up to 192 columns in 256 slots, this one
+        // rows up to 320 columns in 128), 32 rows of loads ahead of their stores
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        typedef f4 f4u __attribute__((aligned(4)));
+        const int nq = (p.D - kWave + 3) >> 2;                 // quads per row (<= 64)
+        const bool qa = NCH > 1 && lane < nq;
+        const int qstart = qa ? min(kWave + 4 * lane, p.D - 4) : kWave;   // (> N: market data only)
+        auto quad_src = [&](int de) {
+            return reinterpret_cast<const f4u *>(reinterpret_cast<const char *>(p.panel.info) +
+                                                 (size_t)((unsigned)(de * W + qstart - 1 - N) * 4u));
+        };
+        auto quad_dst = [&](int el) {
+            return reinterpret_cast<f4u *>(reinterpret_cast<char *>(base) +
+                                           (size_t)((unsigned)(el * p.D + qstart) * 4u));
+        };
         if (NCH > 1) {
-            float t[(NCH > 1 ? NCH - 1 : 1) * kWave];
+            for (int g = 0; g < kWave; g += 32) {
+                f4 t[32];
 #pragma unroll
-            for (int el = 0; el < kWave; ++el) {
-                const int de = __builtin_amdgcn_readlane(row_spec, el);
+                for (int j = 0; j < 32; ++j)
+                    t[j] = *quad_src(__builtin_amdgcn_readlane(row_spec, g + j));
 #pragma unroll
-                for (int k = 1; k < NCH; ++k) {
-                    const int col = k * kWave + lane;
-                    const bool ld = k < NCH - 1 || col < p.D;
-                    t[el * (NCH - 1) + k - 1] = *at(p.panel.info, (unsigned)(ld ? de * W + col - 1 - N : 0));
-                }
-            }
+                for (int j = 0; j < 32; ++j) pin(t[j]);
+                if (g == 0) KSTAMP(9);
 #pragma unroll
-            for (int j = 0; j < (NCH - 1) * kWave; ++j) pin(t[j]);
-            KSTAMP(9);
-#pragma unroll
-            for (int el = 0; el < kWave; ++el) {
-                if (el >= nenv_w) continue;
-#pragma unroll
-                for (int k = 1; k < NCH; ++k) {
-                    const int col = k * kWave + lane;
-                    if (k < NCH - 1 || col < p.D) *at(base, (unsigned)(el * p.D + col)) = t[el * (NCH - 1) + k - 1];
-                }
+                for (int j = 0; j < 32; ++j)
+                    if (g + j < nenv_w && qa) *quad_dst(g + j) = t[j];
             }
         }
         KSTAMP(10);
@@ -267,7 +274,7 @@ cashpenalty_kernel(const CpParams p)
         const unsigned long long fix = __ballot(valid && dec != row_spec);
         const int nfix = __builtin_popcountll(fix);
         float t0[kWave];
-        float tf[kFix * (NCH > 1 ? NCH - 1 : 1)];
+        f4 tf[kFix];
         if (W > 0) {
 #pragma unroll
             for (int el = 0; el < kWave; ++el) {
@@ -281,13 +288,7 @@ cashpenalty_kernel(const CpParams p)
                 for (int j = 0; j < kFix; ++j) {
                     const int el = m != 0ull ? __builtin_ctzll(m) : 0;
                     m &= m - 1ull;
-                    const int de = __builtin_amdgcn_readlane(dec, el);
-#pragma unroll
-                    for (int k = 1; k < NCH; ++k) {
-                        const int col = k * kWave + lane;
-                        const bool ld = k < NCH - 1 || col < p.D;
-                        tf[j * (NCH - 1) + k - 1] = *at(p.panel.info, (unsigned)(ld ? de * W + col - 1 - N : 0));
-                    }
+                    tf[j] = *quad_src(__builtin_amdgcn_readlane(dec, el));
                 }
             }
         } else {
@@ -307,11 +308,7 @@ cashpenalty_kernel(const CpParams p)
                 if (m == 0ull) continue;
                 const int el = __builtin_ctzll(m);
                 m &= m - 1ull;
-#pragma unroll
-                for (int k = 1; k < NCH; ++k) {
-                    const int col = k * kWave + lane;
-                    if (k < NCH - 1 || col < p.D) *at(base, (unsigned)(el * p.D + col)) = tf[j * (NCH - 1) + k - 1];
-                }
+                if (qa) *quad_dst(el) = tf[j];
             }
             if (m != 0ull) cp_write_rows<true>(p.obs, p, e0, nenv_w, dec, m, rows, lane);
         }
@@ -666,12 +663,11 @@ int finenv_cashpenalty_step(finenv_cashpenalty *h, const float *actions, float *
             hipLaunchKernelGGL((cashpenalty_kernel<false, NCH_, false>), grid, block, 0,         \
                                (hipStream_t)stream, p);                                          \
     } while (0)
-    switch (nch) {
-    case 1: CP_LAUNCH(1); break;
-    case 2: CP_LAUNCH(2); break;
-    case 3: CP_LAUNCH(3); break;
-    default: CP_LAUNCH(0); break;
-    }
+    // NCH_: 1 = rows of one chunk, 2 = rows of up to 320 columns (streamer copies the market data as
+    // 16-byte quads), 0 = wider rows (one-wave form)
+    if (nch == 1) CP_LAUNCH(1);
+    else if (h->D <= kWave + 4 * kWave) CP_LAUNCH(2);
+    else CP_LAUNCH(0);
 #undef CP_LAUNCH
     return kp_check(h, "cashpenalty_step");
 }

@@ -8,7 +8,7 @@
 // (1) previous-state reward terms, (2) transactions + stop-loss override + cash test inputs,
 // (3) book update.  Sums run in asset order, like the oracle.
 //
-// Observation rows of up to 192 columns (stoploss_step2_kernel): one 128-thread block per 64 envs,
+// Observation rows of up to 320 columns (stoploss_step2_kernel): one 128-thread block per 64 envs,
 // two specialised waves --
 //   wave 0 "trader"  : passes 1 and 2 over every asset, the cash decision, pass 3 for assets
 //                      0..15, scalars, terminal observation / auto-reset.
@@ -137,7 +137,7 @@ __device__ __forceinline__ void sl_write_rows(float *__restrict__ dst, const SlP
         [=](int col) { return col <= N ? col : -1; });
 }
 
-// The one-wave kernel: reset, and steps whose observation rows are wider than 192 columns.
+// The one-wave kernel: reset, and steps whose observation rows are wider than 320 columns.
 template <bool RESET_ONLY>
 __global__ void __launch_bounds__(kWave *kWaves, 1) stoploss_kernel(const SlParams p)
 {
@@ -547,28 +547,33 @@ stoploss_step2_kernel(const SlParams p)
         SSTAMP(9);
         const unsigned long long valid_mask = __ballot(valid);
         float *const base = p.obs + (size_t)e0 * p.D;
+        // market-data columns [64, D) of every row (NCH == 2: 64 < D <= 320): ONE 16-byte-per-lane load
+        // and store per row at 4-byte aligned addresses, the last quad shifted back to end at D; 32
+        // rows of loads ahead of their stores (see finenv_cashpenalty.hip)
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        typedef f4 f4u __attribute__((aligned(4)));
+        const int nq = (p.D - kWave + 3) >> 2;                 // quads per row (<= 64)
+        const bool qa = NCH > 1 && lane < nq;
+        const int qstart = qa ? min(kWave + 4 * lane, p.D - 4) : kWave;   // (> N: market data only)
+        auto quad_src = [&](int de) {
+            return reinterpret_cast<const f4u *>(reinterpret_cast<const char *>(p.panel.info) +
+                                                 (size_t)((unsigned)(de * W + qstart - 1 - N) * 4u));
+        };
+        auto quad_dst = [&](int el) {
+            return reinterpret_cast<f4u *>(reinterpret_cast<char *>(base) +
+                                           (size_t)((unsigned)(el * p.D + qstart) * 4u));
+        };
         if (NCH > 1) {
-            float t[(NCH > 1 ? NCH - 1 : 1) * kWave];
+            for (int g = 0; g < kWave; g += 32) {
+                f4 t[32];
 #pragma unroll
-            for (int el = 0; el < kWave; ++el) {
-                const int de = __builtin_amdgcn_readlane(row_spec, el);
+                for (int j = 0; j < 32; ++j)
+                    t[j] = *quad_src(__builtin_amdgcn_readlane(row_spec, g + j));
 #pragma unroll
-                for (int k = 1; k < NCH; ++k) {
-                    const int col = k * kWave + lane;
-                    const bool ld = k < NCH - 1 || col < p.D;
-                    t[el * (NCH - 1) + k - 1] = *at(p.panel.info, (unsigned)(ld ? de * W + col - 1 - N : 0));
-                }
-            }
+                for (int j = 0; j < 32; ++j) pin(t[j]);
 #pragma unroll
-            for (int j = 0; j < (NCH - 1) * kWave; ++j) pin(t[j]);
-#pragma unroll
-            for (int el = 0; el < kWave; ++el) {
-                if (el >= nenv_w) continue;
-#pragma unroll
-                for (int k = 1; k < NCH; ++k) {
-                    const int col = k * kWave + lane;
-                    if (k < NCH - 1 || col < p.D) *at(base, (unsigned)(el * p.D + col)) = t[el * (NCH - 1) + k - 1];
-                }
+                for (int j = 0; j < 32; ++j)
+                    if (g + j < nenv_w && qa) *quad_dst(g + j) = t[j];
             }
         }
         SSTAMP(10);
@@ -589,7 +594,7 @@ stoploss_step2_kernel(const SlParams p)
         const unsigned long long fix = __ballot(valid && dec != row_spec);
         const int nfix = __builtin_popcountll(fix);
         float t0[kWave];
-        float tf[kFix * (NCH > 1 ? NCH - 1 : 1)];
+        f4 tf[kFix];
         if (W > 0) {
 #pragma unroll
             for (int el = 0; el < kWave; ++el) {
@@ -603,13 +608,7 @@ stoploss_step2_kernel(const SlParams p)
                 for (int j = 0; j < kFix; ++j) {
                     const int el = m != 0ull ? __builtin_ctzll(m) : 0;
                     m &= m - 1ull;
-                    const int de = __builtin_amdgcn_readlane(dec, el);
-#pragma unroll
-                    for (int k = 1; k < NCH; ++k) {
-                        const int col = k * kWave + lane;
-                        const bool ld = k < NCH - 1 || col < p.D;
-                        tf[j * (NCH - 1) + k - 1] = *at(p.panel.info, (unsigned)(ld ? de * W + col - 1 - N : 0));
-                    }
+                    tf[j] = *quad_src(__builtin_amdgcn_readlane(dec, el));
                 }
             }
         } else {
@@ -652,11 +651,7 @@ stoploss_step2_kernel(const SlParams p)
                 if (m == 0ull) continue;
                 const int el = __builtin_ctzll(m);
                 m &= m - 1ull;
-#pragma unroll
-                for (int k = 1; k < NCH; ++k) {
-                    const int col = k * kWave + lane;
-                    if (k < NCH - 1 || col < p.D) *at(base, (unsigned)(el * p.D + col)) = tf[j * (NCH - 1) + k - 1];
-                }
+                if (qa) *quad_dst(el) = tf[j];
             }
             if (m != 0ull) sl_write_rows<true>(p.obs, p, e0, nenv_w, dec, m, rows, lane);
         }
@@ -1072,12 +1067,11 @@ int finenv_stoploss_step(finenv_stoploss *h, const float *actions, float *obs, f
             hipLaunchKernelGGL((stoploss_step2_kernel<NCH_, false>), grid2, block, 0,            \
                                (hipStream_t)stream, p);                                          \
     } while (0)
-    switch ((h->D + kWave - 1) / kWave) {      // chunks per observation row
-    case 1: SL_LAUNCH2(1); break;
-    case 2: SL_LAUNCH2(2); break;
-    case 3: SL_LAUNCH2(3); break;
-    default: hipLaunchKernelGGL((stoploss_kernel<false>), grid, block, 0, (hipStream_t)stream, p); break;
-    }
+    // 1 = rows of one chunk, 2 = rows of up to 320 columns (the streamer copies the market data as
+    // 16-byte quads), wider rows: the one-wave kernel
+    if (h->D <= kWave) SL_LAUNCH2(1);
+    else if (h->D <= kWave + 4 * kWave) SL_LAUNCH2(2);
+    else hipLaunchKernelGGL((stoploss_kernel<false>), grid, block, 0, (hipStream_t)stream, p);
 #undef SL_LAUNCH2
     return sl_check(h, "stoploss_step");
 }

@@ -72,8 +72,10 @@ def test_cashpenalty_hip_matches_reference_fixture(name):
     # nearly every env runs out of cash within a few steps: many more re-decided rows per block than
     # the streamer patches in registers (kFix), and rows on three observation chunks
     dict(E=200, T=40, N=30, C=5, steps=30, hmax=400_000, thr=None, patient=False, disc=False),
-    # rows wider than 192 columns: the trader writes the observation itself (no streamer)
-    dict(E=100, T=20, N=30, C=7, steps=30, hmax=60_000, thr=40.0, patient=False, disc=True)])
+    # 241 columns: the streamer copies the market data as 16-byte quads (rows up to 320 columns)
+    dict(E=100, T=20, N=30, C=7, steps=30, hmax=60_000, thr=40.0, patient=False, disc=True),
+    # 331 columns: wider than that, the trader writes the observation itself (no streamer)
+    dict(E=70, T=16, N=30, C=10, steps=24, hmax=60_000, thr=40.0, patient=False, disc=False)])
 def test_cashpenalty_hip_matches_oracle_random_batch(cfg):
     _need_gpu()
     from finrl_amd.vec_cashpenalty import CashPenaltyPanel, VecCashPenaltyEnv

@@ -79,8 +79,10 @@ def test_stoploss_hip_matches_reference_fixture(name):
     # the streamer patches in registers, rows on three observation chunks, 17..30 assets in its pass 3
     dict(E=200, T=40, N=30, C=5, steps=30, hmax=400_000, thr=None, patient=False, disc=False),
     dict(E=257, T=40, N=20, C=4, steps=60, hmax=30_000, thr=60.0, patient=True, disc=True),
-    # rows wider than 192 columns: the one-wave kernel
-    dict(E=100, T=20, N=30, C=7, steps=30, hmax=60_000, thr=40.0, patient=False, disc=True)])
+    # 241 columns: the streamer copies the market data as 16-byte quads (rows up to 320 columns)
+    dict(E=100, T=20, N=30, C=7, steps=30, hmax=60_000, thr=40.0, patient=False, disc=True),
+    # 331 columns: the one-wave kernel
+    dict(E=70, T=16, N=30, C=10, steps=24, hmax=60_000, thr=40.0, patient=False, disc=False)])
 def test_stoploss_hip_matches_oracle_random_batch(cfg):
     _need_gpu()
     from finrl_amd.vec_cashpenalty import CashPenaltyPanel, VecStopLossEnv
