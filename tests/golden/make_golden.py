@@ -221,6 +221,10 @@ STOCK_SCENARIOS = {
     "n100": dict(seed=21, T=14, N=100, K=2, S=32, variant="O-stable", actions="uniform",
                  turbulence_threshold=45.0, flag_frac=0.03, initial_amount=400_000,
                  shares0=np.random.default_rng(8).integers(0, 8, 100)),
+    # 50 tickers: the 64-wide kernel variant
+    "n50": dict(seed=22, T=14, N=50, K=3, S=32, variant="O-stable", actions="uniform",
+                turbulence_threshold=45.0, flag_frac=0.04, initial_amount=250_000,
+                shares0=np.random.default_rng(9).integers(0, 8, 50)),
     "long": dict(seed=20, T=400, N=30, K=2, S=900, variant="O-stable", actions="uniform",
                  store_obs=False, turbulence_threshold=75.0),
 }
