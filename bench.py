@@ -24,7 +24,7 @@ inside the timed region -- and at least once per timed region (half way through 
 when no episode ends in it), so that a short scaling run still shows every rank taking part
 (`rccl` in the JSON).
 
-Other workloads (side metrics and BASELINE configs[2..4]): `--env portfolio|crypto|stocknp|
+Other workloads (side metrics and BASELINE configs[2..4]): `--env portfolio|crypto|stocknp|riskpre|
 cashpenalty|stoploss`, `--tickers 100 --turbulence-pct 90` (configs[3] per-GPU slice),
 `--env crypto --envs-per-gpu 32768 --rollout 16` (configs[4] per-GPU slice: steps write straight
 into [n_steps, E, .] rollout buffers, one GAE scan per segment, one hipGraph replay per segment).
@@ -498,10 +498,44 @@ def timed_region(work, steps, warmup, prewarm, world, dist, sync, make_events, g
     return wall, ev0.elapsed_time(ev1), rccl
 
 
+def riskpre_lines(cpu_baseline=True):
+    """Side measurement: the risk precompute -- turbulence index + cov_list -- at the
+    reference's panel sizes, one JSON line per shape; its cpu_baseline leg times the NumPy oracle on a
+    bounded sample of days (the only place outside tests/ and smoke() that runs anything under
+    oracle/, like the env benches' cpu_baseline)."""
+    import time
+    import torch
+    from finrl_amd import riskpre
+    rng = np.random.default_rng(0)
+    for T, N in ((2893, 30), (2893, 100)):
+        close = 100 * np.exp(np.cumsum(rng.normal(0, 0.01, (T, N)), axis=0))
+        ct = torch.from_numpy(close).cuda()
+        for _ in range(2):
+            riskpre.calculate_turbulence(ct)
+            riskpre.rolling_covariance(ct)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        riskpre.calculate_turbulence(ct)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        riskpre.rolling_covariance(ct)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        line = {"shape": [T, N], "turbulence_ms": (t1 - t0) * 1e3, "cov_list_ms": (t2 - t1) * 1e3,
+                "turbulence_days_per_s": (T - 252) / (t1 - t0)}
+        if cpu_baseline:
+            from oracle import riskpre as orc
+            c0 = time.perf_counter()
+            orc.calculate_turbulence(close[:252 + 200])
+            c1 = time.perf_counter()
+            line["numpy_oracle_days_per_s"] = 200 / (c1 - c0)
+        print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--env", default="stock", choices=["stock", "portfolio", "crypto", "stocknp", "cashpenalty",
-                                                       "stoploss"])
+                                                       "stoploss", "riskpre"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3 * N_DAYS)
     ap.add_argument("--warmup", type=int, default=N_DAYS)
@@ -525,6 +559,9 @@ def main():
                     help="collect into [n_steps, E, .] rollout buffers + GAE scan per segment "
                          "(BASELINE configs[4])")
     args = ap.parse_args()
+    if args.env == "riskpre":
+        riskpre_lines(cpu_baseline=not args.no_cpu_baseline)
+        return
 
     import torch
     import torch.distributed as dist
