@@ -60,6 +60,7 @@ struct CrParams {
     int32_t D;
     uint32_t magicN;
     uint32_t magicW;
+    uint32_t magicH;              // ceil(2^32 / (1 + N)): row of a flat index into the [64][1 + N] heads
     // finenv_crypto_step_record: blocks >= env_blocks copy the policy's outputs of this step into
     // the rollout tensors (16-byte elements), beside the env blocks
     int32_t env_blocks;
@@ -123,8 +124,13 @@ __device__ __forceinline__ void cr_write_rows(float *__restrict__ dst, const CrP
 
 // NP = asset count padded to 8 / 16 / 32: the per-asset state lives in statically indexed
 // registers, so the unrolled loops are compiled per padded width (N = 10 runs the 16-wide build)
-template <bool RESET_ONLY, int kWaves, int NP>
-__global__ void __launch_bounds__(kWave *kWaves, 1) crypto_kernel(const CrParams p)
+// TWO: one 128-thread block per 64 envs, wave 0 the env step ("trader"), wave 1 a "streamer" that writes the
+// indicator columns of the 64 next observation rows -- they depend on the time counter alone (:80, :94-97)
+// -- while the trader computes; the trader then writes only the 1 + N head columns.  No hand-off between
+// the two: they write disjoint columns.  (At 32,768 envs the env waves occupy half the chip's SIMDs and the
+// step is one serial chain: assembling and writing the whole rows was its last 2 us.)
+template <bool RESET_ONLY, int kWaves, int NP, bool TWO = false>
+__global__ void __launch_bounds__(kWave *(TWO ? 2 : kWaves), 1) crypto_kernel(const CrParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];   // kWaves * lds_per_wave(D)
     if (!RESET_ONLY && p.env_blocks > 0 && (int)blockIdx.x >= p.env_blocks) {
@@ -144,7 +150,8 @@ __global__ void __launch_bounds__(kWave *kWaves, 1) crypto_kernel(const CrParams
         return;
     }
     const int lane = threadIdx.x & (kWave - 1);
-    const int wib = threadIdx.x >> 6;
+    const int wib = TWO ? 0 : (int)(threadIdx.x >> 6);
+    const int role = TWO ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     float *rows = lds_all + wib * lds_per_wave(p.D);        // [env][kRow]: actions, then obs heads
     const int E = p.cfg.n_envs, N = p.cfg.n_assets;
     const int e0 = (blockIdx.x * kWaves + wib) * kWave;
@@ -153,6 +160,44 @@ __global__ void __launch_bounds__(kWave *kWaves, 1) crypto_kernel(const CrParams
     const bool valid = lane < nenv_w;
     const int e = valid ? e0 + lane : e0;
     float *row = rows + lane * kRow;
+    // full waves whose indicator columns fit one lane-per-column pass: the streamer takes them
+    const int n_ind = p.D - 1 - N;
+    const bool split = TWO && !RESET_ONLY && nenv_w == kWave && n_ind > 0 && n_ind <= kWave;
+    if (TWO && role == 1) {
+        if (!split) return;
+        const int max_step_s = p.cfg.n_steps - p.cfg.lookback - 1;           // :24
+        const int time_s = CI(FINENV_CI_TIME) + 1;                            // :60
+        const bool done_s = time_s == max_step_s;                             // :80
+        const int trow = (done_s && p.auto_reset) ? p.cfg.lookback - 1 : time_s;
+        const int W = p.cfg.n_tech;
+        const bool act = lane < n_ind;
+        const int c2 = act ? lane : 0;
+        const int l = (W == 1) ? c2 : (int)__umulhi((unsigned)c2, p.magicW);   // lookback row, :94-97
+        const int j = c2 - l * W;
+        float *const sb = p.obs + (size_t)e0 * p.D + 1 + N + c2;
+        const int t0 = __builtin_amdgcn_readfirstlane(trow);
+        if (__all(trow == t0)) {
+            const float v = *at(p.panel.tech_scaled, (unsigned)((t0 - l) * W + j));
+#pragma unroll 8
+            for (int el = 0; el < kWave; ++el)
+                if (act) *at(sb, (unsigned)(el * p.D)) = v;
+        } else {
+            for (int g = 0; g < kWave; g += 32) {
+                float v[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) {
+                    const int rd = __builtin_amdgcn_readlane(trow, g + u);
+                    v[u] = *at(p.panel.tech_scaled, (unsigned)((rd - l) * W + j));
+                }
+#pragma unroll
+                for (int u = 0; u < 32; ++u) pin(v[u]);
+#pragma unroll
+                for (int u = 0; u < 32; ++u)
+                    if (act) *at(sb, (unsigned)((g + u) * p.D)) = v[u];
+            }
+        }
+        return;
+    }
 
     if (RESET_ONLY) {                                       // reset(), :48-57
         const bool sel = valid && (p.mask == nullptr || p.mask[e] != 0);
@@ -217,7 +262,7 @@ __global__ void __launch_bounds__(kWave *kWaves, 1) crypto_kernel(const CrParams
             idx = (t_first - l) * W + (c2 - l * W);
         }
         tt[k] = 0.0f;
-        if (W > 0) tt[k] = *at(p.panel.tech_scaled, (unsigned)idx);
+        if (W > 0 && !split) tt[k] = *at(p.panel.tech_scaled, (unsigned)idx);
     }
     wave_sync();
     CSTAMP(2);
@@ -309,7 +354,7 @@ __global__ void __launch_bounds__(kWave *kWaves, 1) crypto_kernel(const CrParams
     // instructions instead of 64.  (A wave can have at most 64 vector-memory operations outstanding;
     // behind the state stores the 64 row stores of the row-wise form stalled on write
     // acknowledgements: 3 us of a 13 us step.)
-    const bool use_blk = fast_obs && nenv_w == kWave && D <= kBlkMaxD && !__any(done && valid);
+    const bool use_blk = !split && fast_obs && nenv_w == kWave && D <= kBlkMaxD && !__any(done && valid);
     float *hrow = use_blk ? rows + lane * D : row;          // where this env's heads go
     wave_sync();
 #pragma unroll
@@ -347,7 +392,18 @@ __global__ void __launch_bounds__(kWave *kWaves, 1) crypto_kernel(const CrParams
         }
     }
     CSTAMP(6);
-    if (use_blk) {
+    if (split) {
+        // the streamer writes the indicator columns; here: the 64 x (1 + N) head values, read back
+        // from LDS in flat order (lane = consecutive columns of a row)
+        const int H = 1 + N, total = kWave * H;
+        float *const hb = p.obs + (size_t)e0 * D;
+#pragma unroll 4
+        for (int idx = lane; idx < total; idx += kWave) {
+            const int r = (int)__umulhi((unsigned)idx, p.magicH);
+            const int cc = idx - r * H;
+            *at(hb, (unsigned)(r * D + cc)) = rows[r * kRow + cc];
+        }
+    } else if (use_blk) {
         // indicator columns: lane = column, the same value in every row
         if (tsel[0] == -1) {
 #pragma unroll 8
@@ -405,7 +461,7 @@ struct finenv_crypto {
     finenv_crypto_state st;
     int bound;
     int D;
-    uint32_t magicN, magicW;
+    uint32_t magicN, magicW, magicH;
     char err[256];
 };
 
@@ -434,6 +490,7 @@ CrParams cr_params(const finenv_crypto *h)
     p.D = h->D;
     p.magicN = h->magicN;
     p.magicW = h->magicW;
+    p.magicH = h->magicH;
     return p;
 }
 uint32_t magic_for(long long n)
@@ -448,10 +505,14 @@ void cr_launch_np(const CrParams &p, hipStream_t stream)
     CrParams q = p;
     const int n4 = p.rec_na4 + 2 * p.rec_nv4;            // record work (0: plain step)
     if (waves <= kSmallWaves) {
-        const int rec_blocks = n4 > 0 ? min(512, (n4 + kWave * 8 - 1) / (kWave * 8)) : 0;
+        const int rec_blocks = n4 > 0 ? min(512, (n4 + kWave * 16 - 1) / (kWave * 16)) : 0;
         q.env_blocks = n4 > 0 ? waves : 0;
-        hipLaunchKernelGGL((crypto_kernel<RESET_ONLY, 1, NP>), dim3((unsigned)(waves + rec_blocks)),
-                           dim3(kWave), sizeof(float) * lds_per_wave(p.D), stream, q);
+        if (RESET_ONLY)
+            hipLaunchKernelGGL((crypto_kernel<RESET_ONLY, 1, NP, false>), dim3((unsigned)(waves + rec_blocks)),
+                               dim3(kWave), sizeof(float) * lds_per_wave(p.D), stream, q);
+        else        // trader + streamer wave per 64 envs
+            hipLaunchKernelGGL((crypto_kernel<RESET_ONLY, 1, NP, true>), dim3((unsigned)(waves + rec_blocks)),
+                               dim3(2 * kWave), sizeof(float) * lds_per_wave(p.D), stream, q);
     } else {
         const int blocks = (waves + 3) / 4;
         const int rec_blocks = n4 > 0 ? min(256, (n4 + kWave * 32 - 1) / (kWave * 32)) : 0;
@@ -491,6 +552,7 @@ int finenv_crypto_create(const finenv_crypto_config *cfg, finenv_crypto **out)
     h->D = (int)D;
     h->magicN = magic_for(N);
     h->magicW = magic_for(W);
+    h->magicH = magic_for(N + 1);
     *out = h;
     return FINENV_OK;
 }
