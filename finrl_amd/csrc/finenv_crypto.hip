@@ -130,7 +130,7 @@ __device__ __forceinline__ void cr_write_rows(float *__restrict__ dst, const CrP
 // the two: they write disjoint columns.  (At 32,768 envs the env waves occupy half the chip's SIMDs and the
 // step is one serial chain: assembling and writing the whole rows was its last 2 us.)
 template <bool RESET_ONLY, int kWaves, int NP, bool TWO = false>
-__global__ void __launch_bounds__(kWave *(TWO ? 2 : kWaves), 1) crypto_kernel(const CrParams p)
+__global__ void __launch_bounds__(kWave *(TWO ? 2 * kWaves : kWaves), 1) crypto_kernel(const CrParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];   // kWaves * lds_per_wave(D)
     if (!RESET_ONLY && p.env_blocks > 0 && (int)blockIdx.x >= p.env_blocks) {
@@ -150,8 +150,9 @@ __global__ void __launch_bounds__(kWave *(TWO ? 2 : kWaves), 1) crypto_kernel(co
         return;
     }
     const int lane = threadIdx.x & (kWave - 1);
-    const int wib = TWO ? 0 : (int)(threadIdx.x >> 6);
-    const int role = TWO ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wib = TWO ? wv % kWaves : wv;                 // env group of this wave within the block
+    const int role = TWO ? wv / kWaves : 0;                 // 0: env step, 1: streamer of the same group
     float *rows = lds_all + wib * lds_per_wave(p.D);        // [env][kRow]: actions, then obs heads
     const int E = p.cfg.n_envs, N = p.cfg.n_assets;
     const int e0 = (blockIdx.x * kWaves + wib) * kWave;
@@ -517,8 +518,12 @@ void cr_launch_np(const CrParams &p, hipStream_t stream)
         const int blocks = (waves + 3) / 4;
         const int rec_blocks = n4 > 0 ? min(256, (n4 + kWave * 32 - 1) / (kWave * 32)) : 0;
         q.env_blocks = n4 > 0 ? blocks : 0;
-        hipLaunchKernelGGL((crypto_kernel<RESET_ONLY, 4, NP>), dim3((unsigned)(blocks + rec_blocks)),
-                           dim3(kWave * 4), sizeof(float) * 4 * lds_per_wave(p.D), stream, q);
+        if (RESET_ONLY)
+            hipLaunchKernelGGL((crypto_kernel<RESET_ONLY, 4, NP, false>), dim3((unsigned)(blocks + rec_blocks)),
+                               dim3(kWave * 4), sizeof(float) * 4 * lds_per_wave(p.D), stream, q);
+        else
+            hipLaunchKernelGGL((crypto_kernel<RESET_ONLY, 4, NP, true>), dim3((unsigned)(blocks + rec_blocks)),
+                               dim3(kWave * 8), sizeof(float) * 4 * lds_per_wave(p.D), stream, q);
     }
 }
 template <bool RESET_ONLY>
