@@ -37,7 +37,7 @@ class StockConfig(C.Structure):
         ("n_envs", C.c_int32), ("n_tickers", C.c_int32), ("n_tech", C.c_int32),
         ("n_days", C.c_int32), ("hmax", C.c_int32), ("use_turbulence", C.c_int32),
         ("reset_quirk", C.c_int32), ("initial", C.c_int32), ("track_stats", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("single_ticker", C.c_int32),
         ("buy_cost_pct", C.c_double), ("sell_cost_pct", C.c_double),
         ("reward_scaling", C.c_double), ("turbulence_threshold", C.c_double),
     ]

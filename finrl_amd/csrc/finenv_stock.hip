@@ -189,6 +189,7 @@ int finenv_stock_create(const finenv_stock_config *cfg, finenv_stock **out)
         cfg->n_tech < 0 || cfg->n_days < 1 || cfg->hmax < 0 ||
         cfg->hmax > (cfg->n_tickers <= 32 ? (1 << 24) : (1 << 22)))
         return FINENV_ERR_INVALID;
+    if (cfg->single_ticker && cfg->n_tickers != 1) return FINENV_ERR_INVALID;
     if ((long long)cfg->n_envs * (1 + 2 * cfg->n_tickers + cfg->n_tech * cfg->n_tickers) >
         (1ll << 40))
         return FINENV_ERR_INVALID;

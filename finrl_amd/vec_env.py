@@ -67,7 +67,9 @@ class VecStockTradingEnv:
 
         self._cfg = nat.StockConfig(
             E, N, K, T, self.hmax, int(turbulence_threshold is not None), int(bool(reset_quirk)),
-            int(bool(initial)), int(bool(track_stats)), 0, float(buy_cost_pct),
+            int(bool(initial)), int(bool(track_stats)),
+            int(N == 1),      # one ticker in the frame: the reference's single-stock branches (:415-422)
+            float(buy_cost_pct),
             float(sell_cost_pct), float(reward_scaling),
             float(turbulence_threshold) if turbulence_threshold is not None else 0.0)
         L = nat.lib()

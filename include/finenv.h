@@ -65,7 +65,12 @@ typedef struct finenv_stock_config {
                                      of asset_memory[0] (:364-378)                       */
     int32_t track_stats;          /* keep running sums of daily returns (Sharpe,
                                      :243-251) on device                                 */
-    int32_t reserved0;
+    int32_t single_ticker;        /* 1 <=> len(df.tic.unique()) == 1 (needs n_tickers == 1):
+                                     the reference's single-stock branches -- with `initial`
+                                     the state starts from `[0] * stock_dim` shares whatever
+                                     num_stock_shares holds (:415-422) while asset_memory[0]
+                                     still counts them (:85-91, :364-370).  0 keeps the
+                                     multi-stock rule for a 1-wide batch                   */
     double  buy_cost_pct;         /* scalar in this fork, :54                            */
     double  sell_cost_pct;        /* :55                                                 */
     double  reward_scaling;       /* :56                                                 */

@@ -40,6 +40,7 @@ class StockCfg(C.Structure):
         ("n_envs", C.c_int32), ("n_tickers", C.c_int32), ("n_tech", C.c_int32),
         ("n_days", C.c_int32), ("hmax", C.c_int32), ("use_turbulence", C.c_int32),
         ("reset_quirk", C.c_int32), ("initial", C.c_int32),
+        ("single_ticker", C.c_int32), ("reserved0", C.c_int32),
         ("buy_cost_pct", C.c_double), ("sell_cost_pct", C.c_double),
         ("reward_scaling", C.c_double), ("turbulence_threshold", C.c_double),
     ]
@@ -71,7 +72,10 @@ class StockOracle:
         self.E, self.N, self.K, self.T = int(n_envs), N, K, T
         self.D = 1 + 2 * N + K * N
         self.cfg = StockCfg(self.E, N, K, T, int(hmax), int(turbulence_threshold is not None),
-                            int(bool(reset_quirk)), int(bool(initial)), float(buy_cost_pct),
+                            int(bool(reset_quirk)), int(bool(initial)),
+                            # one ticker in the frame: the reference's single-stock branches
+                            # (env_stocktrading.py:415-422, :443-450, :470-476)
+                            int(N == 1), 0, float(buy_cost_pct),
                             float(sell_cost_pct), float(reward_scaling),
                             float(turbulence_threshold if turbulence_threshold is not None else 0.0))
         L = lib()

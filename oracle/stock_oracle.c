@@ -39,6 +39,9 @@ typedef struct {
     int32_t use_turbulence;     /* turbulence_threshold is not None, :68             */
     int32_t reset_quirk;        /* 1 = reference stale-row reset (:361 before :380)  */
     int32_t initial;            /* `initial` ctor flag, :70 (asset0 summation order) */
+    int32_t single_ticker;      /* len(df.tic.unique()) == 1: the single-stock branches
+                                   (:415-422: `[0] * stock_dim` shares when initial)  */
+    int32_t reserved0;
     double  buy_cost_pct;       /* scalar in this fork, :54                          */
     double  sell_cost_pct;      /* :55                                               */
     double  reward_scaling;     /* :56                                               */
@@ -166,6 +169,9 @@ void stock_oracle_init(stock_oracle *o, const double *cash0, const int64_t *shar
     memcpy(o->cash0, cash0, E * sizeof(double));
     memcpy(o->shares0, shares0, E * N * sizeof(int64_t));
     memcpy(o->shares, shares0, E * N * sizeof(int64_t));
+    /* single stock, initial=True: state shares are `[0] * stock_dim` whatever
+     * num_stock_shares says (:415-422) -- asset_memory[0] still counts them (:85-91) */
+    if (o->cfg.single_ticker && o->cfg.initial) memset(o->shares, 0, E * N * sizeof(int64_t));
     for (size_t e = 0; e < E; e++) {
         stock_env *s = &o->env[e];
         memset(s, 0, sizeof(*s));
@@ -203,8 +209,11 @@ void stock_oracle_reset_env(stock_oracle *o, int e, double *obs /* [D] or NULL *
     stock_env *s = &o->env[e];
     if (!o->cfg.reset_quirk) s->price_day = 0;
     s->cash = o->cash0[e];
-    memcpy(o->shares + (size_t)e * N, o->shares0 + (size_t)e * N, N * sizeof(int64_t));
-    s->asset0 = initial_asset(o, e, s->price_day);
+    if (o->cfg.single_ticker && o->cfg.initial)                              /* :415-422 */
+        memset(o->shares + (size_t)e * N, 0, N * sizeof(int64_t));
+    else
+        memcpy(o->shares + (size_t)e * N, o->shares0 + (size_t)e * N, N * sizeof(int64_t));
+    s->asset0 = initial_asset(o, e, s->price_day);        /* num_stock_shares, :364-370 */
     s->prev_asset = s->asset0;
     s->ret_sum = 0.0; s->ret_sumsq = 0.0; s->n_ret = 0;
     if (obs) write_obs(o, e, s->price_day, obs);

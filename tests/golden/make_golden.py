@@ -227,6 +227,18 @@ STOCK_SCENARIOS = {
                 shares0=np.random.default_rng(9).integers(0, 8, 50)),
     "long": dict(seed=20, T=400, N=30, K=2, S=900, variant="O-stable", actions="uniform",
                  store_obs=False, turbulence_threshold=75.0),
+    # single ticker: the reference's own single-stock branches (:417-422 `[0] * stock_dim` shares
+    # whatever num_stock_shares says while asset_memory[0] still counts them :85-91 / :364-370;
+    # :443-450, :470-476 scalar row access; :337-341 turbulence; :480-485 date)
+    "n1": dict(seed=31, T=18, N=1, K=3, S=45, variant="O-stable", actions="uniform",
+               initial_amount=5_000, hmax=30),
+    "n1_shares": dict(seed=32, T=18, N=1, K=3, S=45, variant="O-stable", actions="uniform",
+                      initial_amount=5_000, hmax=30, shares0=[7]),
+    "n1_turb": dict(seed=33, T=18, N=1, K=2, S=45, variant="O-stable", actions="uniform",
+                    initial_amount=4_000, hmax=25, shares0=[5], turbulence_threshold=30.0,
+                    flag_frac=0.1),
+    "n1_prevstate": dict(seed=34, T=18, N=1, K=3, S=45, variant="O-stable", actions="uniform",
+                         initial_amount=6_000, hmax=30, shares0=[9], previous_state=True),
 }
 
 

@@ -24,7 +24,7 @@ def test_documented_ctypes_stub_runs_and_matches():
 
     class Cfg(C.Structure):                      # finenv_stock_config
         _fields_ = [(n, C.c_int32) for n in ("n_envs", "n_tickers", "n_tech", "n_days", "hmax",
-                    "use_turbulence", "reset_quirk", "initial", "track_stats", "reserved0")] + \
+                    "use_turbulence", "reset_quirk", "initial", "track_stats", "single_ticker")] + \
                    [(n, C.c_double) for n in ("buy_cost_pct", "sell_cost_pct", "reward_scaling",
                     "turbulence_threshold")]
 

@@ -243,7 +243,8 @@ def test_sb3_adapter_protocol():
     assert saw_done
 
 
-@pytest.mark.parametrize("name", ["tiefree", "ties", "turbulence", "cashbound", "n2", "prevstate"])
+@pytest.mark.parametrize("name", ["tiefree", "ties", "turbulence", "cashbound", "n2", "prevstate",
+                                  "n1", "n1_shares", "n1_turb", "n1_prevstate"])
 def test_gym_facade_is_drop_in(name, capsys):
     """finrl_amd.meta.env_stock_trading.env_stocktrading.StockTradingEnv built from the SAME
     DataFrame and kwargs as the reference env: float64 list observations, rewards, asset /
@@ -290,7 +291,8 @@ def test_gym_facade_is_drop_in(name, capsys):
             am = env.save_asset_memory()
             assert list(am.columns) == ["date", "account_value"] and len(am) == T
             acts = env.save_action_memory()
-            assert acts.shape == (T - 1, N)
+            # single ticker: a {"date", "actions"} frame (:536-542), else one column per ticker
+            assert acts.shape == ((T - 1, N) if N > 1 else (T - 1, 2))
             tj += 1
             obs = env.reset()
             np.testing.assert_array_equal(np.asarray(obs, dtype=np.float64), resets[s])
