@@ -3,7 +3,10 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched as
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per
-GPU, RCCL).  Prints ONE JSON line on rank 0.
+GPU, RCCL).  Prints ONE JSON line on rank 0.  Started WITHOUT a torchrun environment and with
+`--gpus N > 1`, it launches that very command itself as a child process (before anything touches
+the GPU; never by exec) and exits with the child's code -- rank 0's JSON line arrives on the
+inherited stdout.
 
 Workload = BASELINE.json configs[1]: 65,536 vectorised StockTradingEnv per GPU, DOW30 x 8
 indicators, T = 2893 days (Stock_NeurIPS2018 split), uniform(-1,1) random actions, synthetic
@@ -532,10 +535,58 @@ def riskpre_lines(cpu_baseline=True):
         print(json.dumps(line), flush=True)
 
 
-def main():
+class _SelfTestWork(Workload):
+    """`--env launcher-selftest`: no kernel, no GPU -- a counter that follows the Workload protocol
+    so that the launch / rendezvous / gather / JSON plumbing of the N > 1 path can be run where no
+    GPU exists (gloo on the CPU; tests/test_distributed_cpu.py).  Its `value` measures nothing."""
+
+    def __init__(self, torch, E, rank, episode_len):
+        self.torch, self.E, self.rank, self.episode_len = torch, E, rank, episode_len
+        self.n = 0
+        self.kind = "launcher-selftest"
+
+    def step(self, i):
+        self.n += 1
+
+    def reset(self):
+        pass
+
+    def episode_return(self):
+        return self.torch.arange(self.E, dtype=self.torch.float32) + self.rank * self.E
+
+
+class _HostEvent:
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+def self_launch(n_ranks, argv):
+    """`bench.py --gpus N` (N > 1) outside torchrun: run the driver's own command shape as a CHILD
+    process -- one rank per GPU, rendezvous on 127.0.0.1 -- and return its exit code.  The parent
+    has not imported torch, let alone touched the GPU; stdout / stderr are inherited, so rank 0's
+    JSON line is this process's output."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what the host driver supports
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--env", default="stock", choices=["stock", "portfolio", "crypto", "stocknp", "cashpenalty",
-                                                       "stoploss", "riskpre"])
+                                                       "stoploss", "riskpre", "launcher-selftest"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3 * N_DAYS)
     ap.add_argument("--warmup", type=int, default=N_DAYS)
@@ -558,43 +609,67 @@ def main():
     ap.add_argument("--rollout", type=int, default=0,
                     help="collect into [n_steps, E, .] rollout buffers + GAE scan per segment "
                          "(BASELINE configs[4])")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.env == "riskpre":
         riskpre_lines(cpu_baseline=not args.no_cpu_baseline)
-        return
+        return 0
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        return self_launch(args.gpus, argv)        # before torch is imported: nothing has touched the GPU
 
     import torch
     import torch.distributed as dist
 
+    selftest = args.env == "launcher-selftest"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start N ranks with torchrun, or "
+                         "run `bench.py --gpus N` without a torchrun environment (it launches them)")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local_rank)
+        if selftest:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cpu") if selftest else torch.device("cuda", local_rank)
     prewarm = args.prewarm if args.prewarm is not None else \
         (PREWARM_DEFAULT if args.warmup < 1024 else 0)
 
-    work = build_workload(args, torch, dev, rank)
+    if selftest:
+        work = _SelfTestWork(torch, min(args.envs_per_gpu, 1024), rank, episode_len=None)
+        prewarm = 0
+    else:
+        work = build_workload(args, torch, dev, rank)
     work.reset()
     if getattr(work, "after_reset", None):
         work.after_reset()
 
     def make_events():
+        if selftest:
+            return _HostEvent(), _HostEvent()
         return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     wall, dev_ms, rccl = timed_region(work, args.steps, args.warmup, prewarm, world, dist,
-                                      torch.cuda.synchronize, make_events,
-                                      global_envs=world * work.E)
+                                      (lambda: None) if selftest else torch.cuda.synchronize,
+                                      make_events, global_envs=world * work.E)
     if world > 1:
         tt = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
 
-    if rank == 0:
+    if rank == 0 and selftest:
+        print(json.dumps({"metric": "launcher self-test (no kernel runs; value is meaningless)",
+                          "value": world * work.E * args.steps / wall, "unit": "stub-steps/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": wall * 1e3 / args.steps, "data": "stub",
+                          "config": {"workload": "launcher-selftest", "envs_per_gpu": work.E,
+                                     "global_envs": world * work.E},
+                          "rccl": rccl, "stub_steps_run": work.n}), flush=True)
+    elif rank == 0:
         E = work.E
         per_launch_s = dev_ms * 1e-3 / args.steps        # HIP events on the launch stream
         achieved = work.B * E / per_launch_s / 1e9
@@ -632,7 +707,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -98,23 +98,29 @@ def gather_episode_returns(local_returns, global_envs: int = None, group=None, a
     env steps launched meanwhile overlap with it, ``handle.wait()`` yields the gathered tensor.
 
     local_returns: 1-D tensor (this rank's envs, in local order).  Returns a 1-D tensor of
-    length sum(shard sizes) on the same device, identical on every rank.  Which collective runs
-    is decided by ARITHMETIC that every rank evaluates identically (never by catching an error on
-    one rank, which would leave the ranks in different collectives): equal shards -- global_envs
-    omitted or divisible by the world size -- use one `all_gather_into_tensor` (a single RCCL
-    all-gather; gloo implements it too); ragged shards pad to the largest shard and use the list
-    form.
+    length global_envs on the same device, identical on every rank.  With more than one rank
+    ``global_envs`` is REQUIRED: the shape of the collective is derived from it alone, by
+    arithmetic every rank evaluates identically (never from the local tensor's size, and never by
+    catching an error on one rank -- either would leave the ranks in different collectives):
+    equal shards (global_envs divisible by the world size) use one `all_gather_into_tensor` (a
+    single RCCL all-gather; gloo implements it too); ragged shards pad to the largest shard and use
+    the list form.  A rank whose tensor does not have shard_range(global_envs, rank, world) entries
+    raises before entering the collective.
     """
     import torch
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         out = local_returns.clone()
         return _PendingGather(out, None) if async_op else out
-    world = dist.get_world_size(group)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     n = local_returns.numel()
-    if global_envs is None or global_envs % world == 0:
-        if global_envs is not None and n * world != global_envs:
-            raise ValueError(f"rank holds {n} envs, expected {global_envs // world}")
+    if global_envs is None:
+        raise ValueError("gather_episode_returns: global_envs is required when world > 1 "
+                         "(ragged shards cannot be told from equal ones locally)")
+    lo, hi = shard_range(global_envs, rank, world)
+    if n != hi - lo:
+        raise ValueError(f"rank {rank} holds {n} envs, its shard of {global_envs} has {hi - lo}")
+    if global_envs % world == 0:
         out = torch.empty(n * world, dtype=local_returns.dtype, device=local_returns.device)
         work = dist.all_gather_into_tensor(out, local_returns.contiguous(), group=group,
                                            async_op=async_op)

@@ -48,10 +48,13 @@ class RolloutBuffer:
         env can record them itself (`supports_record`: finenv_crypto_step_record), else two."""
         import torch
         out = (self.obs[t + 1], self.rewards[t], self.dones[t])
-        fused = getattr(env, "supports_record", False) and self.num_envs % 4 == 0 and \
-            (self.num_envs * self.actions.shape[2]) % 4 == 0 and \
-            all(x.dtype == torch.float32 and x.is_contiguous() and x.data_ptr() % 16 == 0
-                for x in (actions, values, log_probs))
+        dev, E, A = self.rewards.device, self.num_envs, self.actions.shape[2]
+        # anything the one-launch form cannot take (other device, dtype, layout, size, alignment)
+        # goes through put(), which converts, + a plain step
+        fused = getattr(env, "supports_record", False) and E % 4 == 0 and (E * A) % 4 == 0 and \
+            all(torch.is_tensor(x) and x.device == dev and x.dtype == torch.float32 and
+                x.is_contiguous() and x.data_ptr() % 16 == 0 and x.numel() == n
+                for x, n in ((actions, E * A), (values, E), (log_probs, E)))
         if fused:
             env.step(actions, out=out, record=(values, log_probs, self.actions[t], self.values[t],
                                                self.log_probs[t]))

@@ -55,6 +55,17 @@ class CryptoOracle:
         lib().cr_oracle_reset(self._h, _p(obs))
         return obs
 
+    def reset_masked(self, mask):
+        """reset() (:48-57) for the envs with mask[e] != 0 only -> their observation rows
+        (rows of the other envs are left zero)."""
+        obs = np.zeros((self.E, self.D), dtype=np.float32)
+        L = lib()
+        for e in np.flatnonzero(np.asarray(mask)):
+            row = np.empty(self.D, dtype=np.float32)
+            L.cr_oracle_reset_env(self._h, C.c_int(int(e)), _p(row))
+            obs[e] = row
+        return obs
+
     def vec_step(self, actions, auto_reset=True):
         a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.E, self.N)
         obs = np.empty((self.E, self.D), dtype=np.float32)

@@ -157,3 +157,43 @@ def test_every_env_kind_shards():
     n, kw = shard_env_kwargs(10, 2, 3, initial_capital=np.arange(10.0), gamma=0.9)
     assert n == 3 and kw["gamma"] == 0.9
     np.testing.assert_array_equal(kw["initial_capital"], np.arange(10.0)[7:10])
+
+
+# ---------------------------------------------------------------------------------------------
+# `python bench.py --gpus N` outside torchrun starts its own ranks (the shape of the driver's
+# single-GPU command with N > 1): a child `python -m torch.distributed.run ... bench.py`, never an
+# exec, before torch is imported.  `--env launcher-selftest` swaps the kernels for a counter and
+# RCCL for gloo, so the launch / rendezvous / gather / JSON plumbing runs where no GPU exists.
+# ---------------------------------------------------------------------------------------------
+def _run_bench(args, env_extra=None, timeout=600):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, cwd="/tmp",
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_self_launches_its_ranks():
+    r, out = _run_bench(["--gpus", "2", "--env", "launcher-selftest", "--steps", "6", "--warmup", "2"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out is not None and out["n_gpus"] == 2 and out["steps"] == 6
+    assert out["rccl"] == dict(world=2, backend="gloo", gathers=1, gathered=2 * out["config"]["envs_per_gpu"])
+    assert out["config"]["global_envs"] == 2 * out["config"]["envs_per_gpu"]
+    assert out["stub_steps_run"] == 8            # warm-up + timed steps, once per rank
+    assert sum(ln.startswith("{") for ln in r.stdout.splitlines()) == 1     # rank 0 only
+
+
+def test_bench_single_rank_and_world_mismatch():
+    r, out = _run_bench(["--gpus", "1", "--env", "launcher-selftest", "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0 and out["n_gpus"] == 1 and out["rccl"] is None
+    # inside a (here: one-rank) torchrun environment the ranks are the launcher's business:
+    # a --gpus that disagrees with WORLD_SIZE is an error message, not an assert
+    r, out = _run_bench(["--gpus", "2", "--env", "launcher-selftest", "--steps", "3", "--warmup", "1"],
+                        env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and out is None and "WORLD_SIZE=1" in r.stderr

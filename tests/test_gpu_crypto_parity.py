@@ -64,7 +64,11 @@ def test_crypto_hip_matches_reference_fixture(name):
                                  # observation block path: D = 64 (even), D = 65 (row-wise path)
                                  dict(E=200, T=20, N=17, W=5, L=1, steps=45),
                                  dict(E=128, T=20, N=16, W=47, L=1, steps=45),
-                                 dict(E=70, T=20, N=8, W=56, L=1, steps=45)])
+                                 dict(E=70, T=20, N=8, W=56, L=1, steps=45),
+                                 # more than 64 indicator columns: the trader + streamer kernel
+                                 # without the column split (whole rows from the env wave)
+                                 dict(E=192, T=20, N=10, W=40, L=2, steps=45),
+                                 dict(E=256, T=20, N=20, W=33, L=3, steps=45)])
 def test_crypto_hip_matches_oracle_random_batch(cfg):
     _need_gpu()
     from finrl_amd.vec_crypto import VecCryptoEnv
@@ -216,3 +220,97 @@ def test_crypto_step_record_matches_put_plus_step():
     v, lp = torch.randn(140_000, device="cuda"), torch.randn(140_000, device="cuda")
     buf.step(big, 0, a, v, lp)
     assert torch.equal(buf.actions[0], a) and torch.equal(buf.values[0], v) and torch.equal(buf.log_probs[0], lp)
+
+
+def _crypto_panel(rng, T, N, W):
+    price = 10.0 ** rng.uniform(-1, 4.5, N) * np.exp(
+        np.cumsum(rng.normal(0, 0.004, (T, N)), axis=0))
+    return price, rng.normal(0, 3000, (T, W))
+
+
+def _assert_crypto_state_equal(env, orc, tag):
+    st, os_ = env.state_numpy(), orc.state()
+    for k in ("cash", "total_asset", "gamma_return", "episode_return", "time", "stocks"):
+        np.testing.assert_array_equal(st[k], os_[k], err_msg=f"{k} {tag}")
+
+
+@pytest.mark.parametrize("record", [False, True])
+def test_crypto_large_batch_regime_matches_oracle(record):
+    """E = 140,000 > 131,072 envs: the launch shape of the large-batch regime (the 262,144-env line
+    of bench.py runs it).  Every observation, reward, done flag, terminal observation and state
+    field of every env against the oracle over two episode ends; plain step and step_record."""
+    _need_gpu()
+    from finrl_amd.rollout import RolloutBuffer
+    from finrl_amd.vec_crypto import VecCryptoEnv
+    from oracle.crypto import CryptoOracle
+    E, T, N, W, steps = 140_000, 12, 10, 40, 24
+    rng = np.random.default_rng(77)
+    price, tech = _crypto_panel(rng, T, N, W)
+    kw = dict(initial_capital=2e5, buy_cost_pct=0.0012, sell_cost_pct=0.0008, gamma=0.97)
+    orc = CryptoOracle(price, tech, n_envs=E, **kw)
+    env = VecCryptoEnv({"price_array": price, "tech_array": tech}, E, **kw)
+    env.enable_terminal_obs()
+    buf = RolloutBuffer(steps, E, env.obs_dim, N) if record else None
+    np.testing.assert_array_equal(env.reset().cpu().numpy(), orc.reset())
+    nd = 0
+    for s in range(steps):
+        a = rng.uniform(-1, 1, (E, N)).astype(np.float32)
+        a[rng.random((E, N)) < 0.1] = 0.0
+        o_obs, o_rew, o_done, o_term = orc.vec_step(a)
+        at = torch.from_numpy(a).cuda()
+        if record:
+            v, lp = torch.randn(E, device="cuda"), torch.randn(E, device="cuda")
+            buf.step(env, s, at, v, lp)
+            g_obs, g_rew, g_done = buf.obs[s + 1], buf.rewards[s], buf.dones[s]
+            assert torch.equal(buf.actions[s], at) and torch.equal(buf.values[s], v)
+            assert torch.equal(buf.log_probs[s], lp)
+        else:
+            g_obs, g_rew, g_done, _ = env.step(at)
+        np.testing.assert_array_equal(g_done.cpu().numpy().astype(bool), o_done)
+        np.testing.assert_array_equal(g_obs.cpu().numpy(), o_obs, err_msg=f"obs step {s}")
+        np.testing.assert_array_equal(g_rew.cpu().numpy(), o_rew.astype(np.float32))
+        _assert_crypto_state_equal(env, orc, f"step {s}")
+        if o_done.any():
+            nd += 1
+            np.testing.assert_array_equal(env.term_obs.cpu().numpy()[o_done], o_term[o_done])
+    assert nd >= 2
+
+
+@pytest.mark.parametrize("cfg", [dict(E=1000, T=30, N=10, W=40, L=1),      # column split (streamer)
+                                 dict(E=333, T=30, N=10, W=40, L=2),       # 80 indicator columns
+                                 dict(E=140_000, T=16, N=10, W=40, L=1)])  # large-batch regime
+def test_crypto_masked_reset_desynchronises_envs(cfg):
+    """finenv_crypto_reset(mask) on a random subset in the middle of an episode, then keep stepping:
+    the envs of one wave sit on different `time` values (per-env indicator rows in the streamer, the
+    generic row writer in the env wave), episodes end at different steps."""
+    _need_gpu()
+    from finrl_amd.vec_crypto import VecCryptoEnv
+    from oracle.crypto import CryptoOracle
+    E, T, N, W, L = cfg["E"], cfg["T"], cfg["N"], cfg["W"], cfg["L"]
+    rng = np.random.default_rng(E + L)
+    price, tech = _crypto_panel(rng, T, N, W)
+    kw = dict(lookback=L, initial_capital=5e4, gamma=0.95)
+    orc = CryptoOracle(price, tech, n_envs=E, **kw)
+    env = VecCryptoEnv({"price_array": price, "tech_array": tech}, E, **kw)
+    env.enable_terminal_obs()
+    np.testing.assert_array_equal(env.reset().cpu().numpy(), orc.reset())
+    saw_partial_done = False
+    for s in range(2 * T + 6):
+        if s in (3, 7, 8, T + 5):          # reset 30 % / 50 % / 2 % / 30 % of the envs
+            frac = {3: 0.3, 7: 0.5, 8: 0.02, T + 5: 0.3}[s]
+            mask = rng.random(E) < frac
+            o_rows = orc.reset_masked(mask)
+            g_rows = env.reset(torch.from_numpy(mask.astype(np.uint8))).cpu().numpy()
+            np.testing.assert_array_equal(g_rows[mask], o_rows[mask], err_msg=f"reset at {s}")
+            _assert_crypto_state_equal(env, orc, f"after reset at {s}")
+        a = rng.uniform(-1, 1, (E, N)).astype(np.float32)
+        o_obs, o_rew, o_done, o_term = orc.vec_step(a)
+        g_obs, g_rew, g_done, _ = env.step(torch.from_numpy(a).cuda())
+        np.testing.assert_array_equal(g_done.cpu().numpy().astype(bool), o_done)
+        np.testing.assert_array_equal(g_obs.cpu().numpy(), o_obs, err_msg=f"obs step {s}")
+        np.testing.assert_array_equal(g_rew.cpu().numpy(), o_rew.astype(np.float32))
+        _assert_crypto_state_equal(env, orc, f"step {s}")
+        if o_done.any():
+            saw_partial_done |= not o_done.all()
+            np.testing.assert_array_equal(env.term_obs.cpu().numpy()[o_done], o_term[o_done])
+    assert saw_partial_done and len(np.unique(orc.state()["time"])) > 1

@@ -29,11 +29,17 @@ def test_config2_portfolio_fullsize():
     from finrl_amd.panel import PortfolioPanel
     from finrl_amd.vec_portfolio import VecStockPortfolioEnv
     from oracle.portfolio import PortfolioOracle
+    from finrl_amd.riskpre import rolling_covariance
     E, T, N, K = 65_536, 120, 30, 8
     rng = np.random.default_rng(2)
-    close = 100 * np.exp(np.cumsum(rng.normal(0, 0.01, (T, N)), axis=0))
-    rets = np.diff(np.log(close), axis=0, prepend=np.log(close[:1]))
-    cov = np.einsum("ti,tj->tij", rets, rets).astype(np.float32).astype(np.float64)
+    # the covariance state bench.py feeds: 252-day rolling window of the
+    # returns, computed on the device (finenv_riskpre_rolling_cov), f32-rounded like the frame's
+    # cov_list column; the series runs 252 days longer and the env sees the last T days
+    close = 100 * np.exp(np.cumsum(rng.normal(0, 0.01, (T + 252, N)), axis=0))
+    cov = rolling_covariance(close, lookback=252, device="cuda").cpu().numpy()
+    close = close[252:]                      # cov_list starts at the first full window
+    assert cov.shape == (T, N, N) and np.linalg.matrix_rank(cov[T // 2]) == N
+    cov = cov.astype(np.float32).astype(np.float64)
     tech = rng.normal(0, 1, (T, K, N)).astype(np.float32).astype(np.float64)
     panel = PortfolioPanel(close, cov, tech)
     env = VecStockPortfolioEnv(panel, E, initial_amount=1e6, auto_reset=True)
