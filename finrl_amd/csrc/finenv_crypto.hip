@@ -35,15 +35,11 @@ namespace {
 
 typedef float wide4 __attribute__((ext_vector_type(4)));
 constexpr int kWave = 64;
-constexpr int kMaxN = FINENV_CRYPTO_MAX_ASSETS;
-constexpr int kRow = kMaxN + 1;                 // odd row stride (dwords)
-constexpr int kBlkMaxD = 64;                    // observation rows up to this width are assembled in LDS
-constexpr int kLdsRows = kWave * kRow;          // dwords: [env][kRow] action rows, then obs heads; the
-                                                // wave's observation block [64][D] reuses the region
-__host__ __device__ constexpr int lds_per_wave(int D)       // dwords of dynamic LDS per wave
-{
-    return (D <= kBlkMaxD && kWave * D > kLdsRows) ? kWave * D : kLdsRows;
-}
+constexpr int kBlkMaxD = 64;                    // observation rows up to this width: block form (below)
+// LDS per wave (dwords): [env][NP + 1] action rows, later the observation heads (odd row stride);
+// [64] the indicator values of the wave's common observation row (block form); [64] the wave's time
+// counters, published by the env wave for its streamer.
+__host__ __device__ constexpr int lds_per_wave(int NP) { return kWave * (NP + 1) + 2 * kWave; }
 constexpr int kObsChunks = 4;                   // observation chunks preloaded on the fast path
 
 struct CrParams {
@@ -61,6 +57,7 @@ struct CrParams {
     uint32_t magicN;
     uint32_t magicW;
     uint32_t magicH;              // ceil(2^32 / (1 + N)): row of a flat index into the [64][1 + N] heads
+    uint32_t magicD;              // ceil(2^32 / D): row of a flat index into the wave's [64][D] block
     // finenv_crypto_step_record: blocks >= env_blocks copy the policy's outputs of this step into
     // the rollout tensors (16-byte elements), beside the env blocks
     int32_t env_blocks;
@@ -103,17 +100,17 @@ __device__ __forceinline__ double cr_floordiv(double a, double d)   // exact flo
     return q;
 }
 
-// rows[el*kRow + 0] = f32(cash * 2^-18), rows[el*kRow + 1 + i] = stocks_i * 2^-3   (:93)
+// rows[el*stride + 0] = f32(cash * 2^-18), rows[el*stride + 1 + i] = stocks_i * 2^-3   (:93)
 // columns >= 1 + N: tech_scaled[(t_el - l) * W + j]                              (:94-97)
 __device__ __forceinline__ void cr_write_rows(float *__restrict__ dst, const CrParams &p,
                                               int e0, int nenv_w, int t_row,
                                               unsigned long long lane_mask, const float *rows,
-                                              int lane)
+                                              int row_stride, int lane)
 {
     const int N = p.cfg.n_assets, W = p.cfg.n_tech, D = p.D;
     const unsigned magicW = p.magicW;
     write_obs_rows_generic<8, 16>(
-        dst, p.panel.tech_scaled, D, e0, nenv_w, t_row, lane_mask, rows, kRow, lane,
+        dst, p.panel.tech_scaled, D, e0, nenv_w, t_row, lane_mask, rows, row_stride, lane,
         [=](int t, int col) {                                // lookback row l, indicator j
             const int c2 = col - 1 - N;
             const int l = (W == 1) ? c2 : (int)__umulhi((unsigned)c2, magicW);
@@ -122,17 +119,23 @@ __device__ __forceinline__ void cr_write_rows(float *__restrict__ dst, const CrP
         [=](int col) { return col < 1 + N ? col : -1; });
 }
 
-// NP = asset count padded to 8 / 16 / 32: the per-asset state lives in statically indexed
-// registers, so the unrolled loops are compiled per padded width (N = 10 runs the 16-wide build)
+// NP = asset count padded to 8 / 12 / 16 / 32: the per-asset state lives in statically indexed
+// registers, so the unrolled loops are compiled per padded width (N = 10 runs the 12-wide build:
+// <= 128 VGPRs, four env waves per SIMD -- every wave of a 262,144-env batch is resident at once).
 // TWO: one 128-thread block per 64 envs, wave 0 the env step ("trader"), wave 1 a "streamer" that writes the
 // indicator columns of the 64 next observation rows -- they depend on the time counter alone (:80, :94-97)
-// -- while the trader computes; the trader then writes only the 1 + N head columns.  No hand-off between
-// the two: they write disjoint columns.  (At 32,768 envs the env waves occupy half the chip's SIMDs and the
-// step is one serial chain: assembling and writing the whole rows was its last 2 us.)
+// -- while the trader computes; the trader then writes only the 1 + N head columns.  The two write disjoint
+// columns.  The streamer never reads the time counter from memory: the env wave, which owns it, publishes
+// the values it loaded through LDS (one barrier, a round trip after the launch, where the streamer would
+// wait for its own load anyway) and is the only wave that ever touches time[e] -- nothing to order against
+// its write-back at the end of the step, the streamer leaves as soon as its stores are issued.
+// (At 32,768 envs the env waves occupy half the chip's SIMDs and the step is one serial chain: assembling
+// and writing the whole rows was its last 2 us.)
 template <bool RESET_ONLY, int kWaves, int NP, bool TWO = false>
 __global__ void __launch_bounds__(kWave *(TWO ? 2 * kWaves : kWaves), 1) crypto_kernel(const CrParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds_all[];   // kWaves * lds_per_wave(D)
+    constexpr int kRowW = NP + 1;                            // odd row stride of the LDS rows (dwords)
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];   // kWaves * lds_per_wave(NP)
     if (!RESET_ONLY && p.env_blocks > 0 && (int)blockIdx.x >= p.env_blocks) {
         // ---- record blocks (finenv_crypto_step_record): the step's policy outputs -> slice t of
         // the rollout tensors.  At 32,768 envs the env blocks occupy half the SIMDs of the chip and
@@ -153,21 +156,24 @@ __global__ void __launch_bounds__(kWave *(TWO ? 2 * kWaves : kWaves), 1) crypto_
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wib = TWO ? wv % kWaves : wv;                 // env group of this wave within the block
     const int role = TWO ? wv / kWaves : 0;                 // 0: env step, 1: streamer of the same group
-    float *rows = lds_all + wib * lds_per_wave(p.D);        // [env][kRow]: actions, then obs heads
+    float *rows = lds_all + wib * lds_per_wave(NP);         // [env][kRowW]: actions, then obs heads
+    float *ind = rows + kWave * kRowW;                      // [64]: indicator values of the common row
+    int *tpub = reinterpret_cast<int *>(ind + kWave);       // [64]: the wave's time counters (TWO)
     const int E = p.cfg.n_envs, N = p.cfg.n_assets;
     const int e0 = (blockIdx.x * kWaves + wib) * kWave;
-    if (e0 >= E) return;
+    if (e0 >= E) return;                                    // (both roles of the group alike)
     const int nenv_w = min(kWave, E - e0);
     const bool valid = lane < nenv_w;
     const int e = valid ? e0 + lane : e0;
-    float *row = rows + lane * kRow;
+    float *row = rows + lane * kRowW;
     // full waves whose indicator columns fit one lane-per-column pass: the streamer takes them
     const int n_ind = p.D - 1 - N;
     const bool split = TWO && !RESET_ONLY && nenv_w == kWave && n_ind > 0 && n_ind <= kWave;
     if (TWO && role == 1) {
+        lds_barrier();                                       // the env wave has published its time counters
         if (!split) return;
         const int max_step_s = p.cfg.n_steps - p.cfg.lookback - 1;           // :24
-        const int time_s = CI(FINENV_CI_TIME) + 1;                            // :60
+        const int time_s = tpub[lane];                                        // time + 1, :60
         const bool done_s = time_s == max_step_s;                             // :80
         const int trow = (done_s && p.auto_reset) ? p.cfg.lookback - 1 : time_s;
         const int W = p.cfg.n_tech;
@@ -197,9 +203,6 @@ __global__ void __launch_bounds__(kWave *(TWO ? 2 * kWaves : kWaves), 1) crypto_
                     if (act) *at(sb, (unsigned)((g + u) * p.D)) = v[u];
             }
         }
-        // the env waves overwrite the time counter behind this barrier: this wave consumed its copy
-        // long before it gets here (the only ordering the two roles need; it idles here meanwhile)
-        lds_barrier();
         return;
     }
 
@@ -216,16 +219,17 @@ __global__ void __launch_bounds__(kWave *(TWO ? 2 * kWaves : kWaves), 1) crypto_
         row[0] = (float)(p.cfg.initial_cash * 0x1p-18);
         for (int i = 0; i < N; ++i) row[1 + i] = 0.0f;
         wave_sync();
-        cr_write_rows(p.obs, p, e0, nenv_w, t, __ballot(sel), rows, lane);
+        cr_write_rows(p.obs, p, e0, nenv_w, t, __ballot(sel), rows, kRowW, lane);
         return;
     }
 
     CSTAMP(0);
-    // ---- round trip 1: everything that does not depend on `time` ------------------------------
+    // ---- round trip 1: everything that does not depend on `time`; the time counter first (loads
+    // return in order: it is the one value the next round trip -- and the streamer -- wait for) ------
+    const int time = CI(FINENV_CI_TIME) + 1;                                  // :60
     double cash = CF(FINENV_CF_CASH);
     const double prev_asset = CF(FINENV_CF_TOTAL_ASSET);
     double gamma_ret = CF(FINENV_CF_GAMMA_RETURN);
-    const int time = CI(FINENV_CI_TIME) + 1;                                  // :60
     float sv[NP];
     double nrm[NP];
 #pragma unroll
@@ -233,8 +237,20 @@ __global__ void __launch_bounds__(kWave *(TWO ? 2 * kWaves : kWaves), 1) crypto_
         sv[i] = STK(min(i, N - 1));
         nrm[i] = p.panel.norm[min(i, N - 1)];
     }
-    // action tile [nenv_w][N]: coalesced read, transposed through LDS
-    stage_action_tile(rows, kRow, p.actions + (size_t)e0 * N, nenv_w, N, p.magicN, lane);
+    // action tile [nenv_w][N]: coalesced read (NP loads cover 64 x N values), transposed through LDS
+    // once the second round trip is on its way
+    const int a_total = nenv_w * N;
+    const float *const a_src = p.actions + (size_t)e0 * N;
+    float av[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int f = j * kWave + lane;
+        av[j] = *at(a_src, (unsigned)(f < a_total ? f : a_total - 1));
+    }
+    if (TWO) {
+        tpub[lane] = time;
+        lds_barrier();                    // the streamer takes the time counters from here
+    }
     CSTAMP(1);
     const int max_step = p.cfg.n_steps - p.cfg.lookback - 1;                  // :24
     const bool done = time == max_step;                                       // :80
@@ -267,6 +283,15 @@ __global__ void __launch_bounds__(kWave *(TWO ? 2 * kWaves : kWaves), 1) crypto_
         }
         tt[k] = 0.0f;
         if (W > 0 && !split) tt[k] = *at(p.panel.tech_scaled, (unsigned)idx);
+    }
+    // the action tile has landed (its loads are older than the price loads): transpose it
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int f = j * kWave + lane;
+        if (f < a_total) {
+            const int el = (N == 1) ? f : (int)__umulhi((unsigned)f, p.magicN);
+            rows[el * kRowW + (f - el * N)] = av[j];
+        }
     }
     wave_sync();
     CSTAMP(2);
@@ -352,22 +377,24 @@ __global__ void __launch_bounds__(kWave *(TWO ? 2 * kWaves : kWaves), 1) crypto_
 
     CSTAMP(5);
     // ---- observation heads -> LDS; state write-back ------------------------------------------
-    // Block form (full wave, lock-step, nobody done, D <= 64): the wave's 64 observation rows are ONE
-    // contiguous [64][D] block of the output; it is assembled in LDS in its final layout (over the
-    // dead action rows) and written with 16-B-per-lane coalesced stores: 64*D/256 store
-    // instructions instead of 64.  (A wave can have at most 64 vector-memory operations outstanding;
-    // behind the state stores the 64 row stores of the row-wise form stalled on write
-    // acknowledgements: 3 us of a 13 us step.)
+    // Block form (full wave, lock-step, nobody done, D <= 64, no streamer): the wave's 64 observation
+    // rows are ONE contiguous [64][D] block of the output, written with 16-B-per-lane coalesced
+    // stores: 64*D/256 store instructions instead of 64, every 64-byte segment written once and
+    // whole.  (A wave can have at most 64 vector-memory operations outstanding; behind the state
+    // stores the 64 row stores of the row-wise form stalled on write acknowledgements: 3 us of a
+    // 13 us step.)  Each lane assembles its 16 bytes from the heads [64][kRowW] and the 64 indicator
+    // values of the common row, both in LDS: no [64][D] image is built (13 KB per wave at D = 51 --
+    // it capped the residency at 12 waves per CU).
     const bool use_blk = !split && fast_obs && nenv_w == kWave && D <= kBlkMaxD && !__any(done && valid);
-    float *hrow = use_blk ? rows + lane * D : row;          // where this env's heads go
     wave_sync();
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         if (i >= N) continue;
-        hrow[1 + i] = sv[i] * 0x1p-3f;
+        row[1 + i] = sv[i] * 0x1p-3f;
         if (valid) STK(i) = (done && p.auto_reset) ? 0.0f : sv[i];
     }
-    hrow[0] = (float)(cash * 0x1p-18);
+    row[0] = (float)(cash * 0x1p-18);
+    if (use_blk) ind[lane] = tt[0];                          // lane = column (D <= 64: one chunk)
     if (valid) {
         *at(p.reward, (unsigned)e) = (float)reward;
         *at(p.done, (unsigned)e) = done ? 1 : 0;
@@ -382,7 +409,7 @@ __global__ void __launch_bounds__(kWave *(TWO ? 2 * kWaves : kWaves), 1) crypto_
     double cash_out = cash, asset_out = next;
     if (done_mask != 0ull) {
         if (p.term_obs != nullptr)
-            cr_write_rows(p.term_obs, p, e0, nenv_w, time, done_mask, rows, lane);
+            cr_write_rows(p.term_obs, p, e0, nenv_w, time, done_mask, rows, kRowW, lane);
         if (p.auto_reset) {                                                   // reset(), :48-57
             wave_sync();
             if (done) {
@@ -405,20 +432,25 @@ __global__ void __launch_bounds__(kWave *(TWO ? 2 * kWaves : kWaves), 1) crypto_
         for (int idx = lane; idx < total; idx += kWave) {
             const int r = (int)__umulhi((unsigned)idx, p.magicH);
             const int cc = idx - r * H;
-            *at(hb, (unsigned)(r * D + cc)) = rows[r * kRow + cc];
+            *at(hb, (unsigned)(r * D + cc)) = rows[r * kRowW + cc];
         }
     } else if (use_blk) {
-        // indicator columns: lane = column, the same value in every row
-        if (tsel[0] == -1) {
-#pragma unroll 8
-            for (int el = 0; el < kWave; ++el) rows[el * D + lane] = tt[0];
-        }
-        wave_sync();
-        const wide4 *src = reinterpret_cast<const wide4 *>(rows);
+        // flat float f of the block = row f / D, column f % D: a head value of that env, or the
+        // indicator value of that column
+        const int H = 1 + N, n4 = kWave * D / 4;
         wide4 *dst4 = reinterpret_cast<wide4 *>(p.obs + (size_t)e0 * D);
-        const int n4 = kWave * D / 4;
-#pragma unroll 4
-        for (int j = lane; j < n4; j += kWave) dst4[j] = src[j];
+#pragma unroll 2
+        for (int j = lane; j < n4; j += kWave) {
+            wide4 v;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = 4 * j + u;
+                const int r = (int)__umulhi((unsigned)f, p.magicD);
+                const int cc = f - r * D;
+                v[u] = rows[cc < H ? r * kRowW + cc : kWave * kRowW + cc];   // (ind = rows + 64 * kRowW)
+            }
+            dst4[j] = v;
+        }
     } else if (fast_obs) {     // store-only: indicator values preloaded, heads from LDS; row-major order
         // (batches of 16 rows: the batch's LDS reads are in flight before its first store; one
         //  row at a time exposed an LDS round trip per row -- 6.1 us for 64 rows)
@@ -433,7 +465,7 @@ __global__ void __launch_bounds__(kWave *(TWO ? 2 * kWaves : kWaves), 1) crypto_
                 if (head) {
 #pragma unroll
                     for (int j = 0; j < kRB; ++j)
-                        hv[j] = rows[min(g + j, kWave - 1) * kRow + (tsel[k] >= 0 ? tsel[k] : 0)];
+                        hv[j] = rows[min(g + j, kWave - 1) * kRowW + (tsel[k] >= 0 ? tsel[k] : 0)];
                 }
 #pragma unroll
                 for (int j = 0; j < kRB; ++j) {
@@ -445,14 +477,13 @@ __global__ void __launch_bounds__(kWave *(TWO ? 2 * kWaves : kWaves), 1) crypto_
             }
         }
     } else {
-        cr_write_rows(p.obs, p, e0, nenv_w, t_row, valid_mask, rows, lane);
+        cr_write_rows(p.obs, p, e0, nenv_w, t_row, valid_mask, rows, kRowW, lane);
     }
     CSTAMP(7);
-    if (split) lds_barrier();             // the streamers have consumed the time counter (they wait here since)
     if (valid) {
         CF(FINENV_CF_CASH) = cash_out;
         CF(FINENV_CF_TOTAL_ASSET) = asset_out;
-        CI(FINENV_CI_TIME) = t_row;
+        CI(FINENV_CI_TIME) = t_row;       // (this wave alone reads and writes time[e])
     }
     CSTAMP(8);
 }
@@ -466,7 +497,7 @@ struct finenv_crypto {
     finenv_crypto_state st;
     int bound;
     int D;
-    uint32_t magicN, magicW, magicH;
+    uint32_t magicN, magicW, magicH, magicD;
     char err[256];
 };
 
@@ -496,44 +527,47 @@ CrParams cr_params(const finenv_crypto *h)
     p.magicN = h->magicN;
     p.magicW = h->magicW;
     p.magicH = h->magicH;
+    p.magicD = h->magicD;
     return p;
 }
 uint32_t magic_for(long long n)
 {
     return n >= 2 ? (uint32_t)(((1ull << 32) + n - 1) / (unsigned long long)n) : 0u;
 }
-constexpr int kSmallWaves = 2048;      // up to here: one wave per block (spread over every CU)
+constexpr int kSmallWaves = 2048;      // up to here: one env wave per block (spread over every CU)
 template <bool RESET_ONLY, int NP>
 void cr_launch_np(const CrParams &p, hipStream_t stream)
 {
     const int waves = (p.cfg.n_envs + kWave - 1) / kWave;
     CrParams q = p;
     const int n4 = p.rec_na4 + 2 * p.rec_nv4;            // record work (0: plain step)
+    const size_t lds1 = sizeof(float) * lds_per_wave(NP);
     if (waves <= kSmallWaves) {
         const int rec_blocks = n4 > 0 ? min(512, (n4 + kWave * 16 - 1) / (kWave * 16)) : 0;
         q.env_blocks = n4 > 0 ? waves : 0;
         if (RESET_ONLY)
             hipLaunchKernelGGL((crypto_kernel<RESET_ONLY, 1, NP, false>), dim3((unsigned)(waves + rec_blocks)),
-                               dim3(kWave), sizeof(float) * lds_per_wave(p.D), stream, q);
+                               dim3(kWave), lds1, stream, q);
         else        // trader + streamer wave per 64 envs
             hipLaunchKernelGGL((crypto_kernel<RESET_ONLY, 1, NP, true>), dim3((unsigned)(waves + rec_blocks)),
-                               dim3(2 * kWave), sizeof(float) * lds_per_wave(p.D), stream, q);
+                               dim3(2 * kWave), lds1, stream, q);
     } else {
         const int blocks = (waves + 3) / 4;
         const int rec_blocks = n4 > 0 ? min(256, (n4 + kWave * 32 - 1) / (kWave * 32)) : 0;
         q.env_blocks = n4 > 0 ? blocks : 0;
-        // (no streamer waves here: with every SIMD holding several env waves already, streamers that
-        //  wait at the end-of-step barrier keep wave slots from the next blocks -- 34.0 vs 29.5 us at
-        //  262,144 envs; without the barrier 27.4 us, but then nothing orders their read of the time
-        //  counter before the env waves' write)
+        // Large batches are bandwidth-, not latency-bound: no streamer waves (a streamer is a wave of
+        // the same kernel and would hold a full wave's registers: half the env waves' residency), the
+        // env wave writes whole rows in the block form.
         hipLaunchKernelGGL((crypto_kernel<RESET_ONLY, 4, NP, false>), dim3((unsigned)(blocks + rec_blocks)),
-                           dim3(kWave * 4), sizeof(float) * 4 * lds_per_wave(p.D), stream, q);
+                           dim3(kWave * 4), 4 * lds1, stream, q);
     }
 }
 template <bool RESET_ONLY>
 void cr_launch(const CrParams &p, hipStream_t stream)
 {
-    if (RESET_ONLY || p.cfg.n_assets <= 8) cr_launch_np<RESET_ONLY, 8>(p, stream);
+    if (RESET_ONLY) cr_launch_np<RESET_ONLY, 32>(p, stream);      // (no per-asset registers: one build)
+    else if (p.cfg.n_assets <= 8) cr_launch_np<RESET_ONLY, 8>(p, stream);
+    else if (p.cfg.n_assets <= 12) cr_launch_np<RESET_ONLY, 12>(p, stream);
     else if (p.cfg.n_assets <= 16) cr_launch_np<RESET_ONLY, 16>(p, stream);
     else cr_launch_np<RESET_ONLY, 32>(p, stream);
 }
@@ -562,6 +596,7 @@ int finenv_crypto_create(const finenv_crypto_config *cfg, finenv_crypto **out)
     h->magicN = magic_for(N);
     h->magicW = magic_for(W);
     h->magicH = magic_for(N + 1);
+    h->magicD = magic_for(D);
     *out = h;
     return FINENV_OK;
 }

@@ -2,7 +2,7 @@
 # every bench line of round 2 on one box (no profiler): gpurun_out/r02/<tag>_*.json
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 TAG=${1:-b}
-O=$ROOT/gpurun_out/r02
+O=$ROOT/gpurun_out/${RDIR:-r03}
 mkdir -p $O
 run() { name=$1; shift; python3 bench.py --no-cpu-baseline "$@" > $O/${TAG}_$name.json 2> $O/${TAG}_$name.err || echo "FAILED $name"; }
 run driver --gpus 1 --steps 20 --warmup 5
