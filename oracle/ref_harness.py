@@ -93,6 +93,10 @@ class _DummyVecEnv:
         # SB3's public signature; the reference calls it with method_name= (models.py:120-121)
         return [getattr(e, method_name)(*method_args, **method_kwargs) for e in self.envs]
 
+    def render(self, mode="human"):
+        # SB3 DummyVecEnv.render: a single env renders itself (models.py:321 relies on it)
+        return self.envs[0].render(mode=mode)
+
     def close(self):
         pass
 
@@ -190,6 +194,29 @@ class _StableNumpy:
 def stable_argsort_patch(module):
     """O-stable oracle: make the env module's ``np.argsort`` stable."""
     module.np = _StableNumpy(np)
+    return module
+
+
+class _LenientPyplot:
+    """matplotlib.pyplot proxy whose ``savefig`` drops the ``index=`` keyword the reference passes
+    (env_stocktrading.py:284-289): matplotlib releases of the reference's day ignored unknown
+    savefig keywords, 3.10 (this image) raises TypeError -- after the three CSV files of the
+    terminal branch are written, before ``step`` returns."""
+
+    def __init__(self, real):
+        object.__setattr__(self, "_real", real)
+
+    def __getattr__(self, name):
+        return getattr(object.__getattribute__(self, "_real"), name)
+
+    def savefig(self, *args, **kwargs):
+        kwargs.pop("index", None)
+        return object.__getattribute__(self, "_real").savefig(*args, **kwargs)
+
+
+def lenient_savefig_patch(module):
+    """Harness-side name substitution (reference files untouched), like stable_argsort_patch."""
+    module.plt = _LenientPyplot(module.plt)
     return module
 
 

@@ -905,6 +905,59 @@ def run_harness(name, *, kind, seed, T, N, K=8, **kw):
                    cfg_int=np.array([T, N, K, n_diff], np.int64),
                    reward=np.asarray(rec["reward"]), cash=np.asarray(rec["cash"]),
                    shares=np.stack(rec["shares"]), realised=np.stack(rec["realised"]))
+    elif kind == "ensemble":
+        # DRLEnsembleAgent's use of the env (models.py:213-230, :272-325): one validation window
+        # (CSV dump read back for the Sharpe ratio), then two trade windows, the second seeded with
+        # initial=False, previous_state=<render() of the first>.  Scalar costs (SURVEY.md headline 5).
+        mod = rh.lenient_savefig_patch(rh.stable_argsort_patch(rh.load_stocktrading()))
+        Tv, Tr = kw.get("Tv", 9), kw.get("Tr", 8)
+        assert T == Tv + 2 * Tr
+        thr = kw.get("turbulence_threshold")
+        close, tech, risk = synth_panel(seed, T, N, K, flag_frac=kw.get("flag_frac", 0.0))
+        names = [f"ind{k}" for k in range(K)]
+        dates = [f"2021-{1 + t // 28:02d}-{1 + t % 28:02d}" for t in range(T)]
+
+        def window(lo, hi):        # data_split: rows of [lo, hi), index re-factorized (preprocessors.py:24-33)
+            return rh.make_stock_frame(close[lo:hi], tech[lo:hi], risk[lo:hi], names,
+                                       risk_col="turbulence", dates=dates[lo:hi])
+        ekw = dict(stock_dim=N, hmax=kw.get("hmax", 100), initial_amount=kw.get("initial_amount", 100_000),
+                   num_stock_shares=[0] * N, buy_cost_pct=1e-3, sell_cost_pct=1e-3, reward_scaling=1e-4,
+                   state_space=1 + 2 * N + K * N, action_space=N, tech_indicator_list=names,
+                   print_verbosity=1)
+        cwd = os.getcwd()
+        work = "/tmp/golden_work_ens"
+        import shutil
+        shutil.rmtree(work, ignore_errors=True)
+        os.makedirs(os.path.join(work, "results"))
+        os.chdir(work)
+        try:
+            with contextlib.redirect_stdout(printed):
+                val = window(0, Tv)
+                model = hl.ScriptedModel(base, 1 + np.arange(N))
+                val_env = rh._DummyVecEnv([lambda: mod.StockTradingEnv(
+                    df=val, turbulence_threshold=thr, iteration=63, model_name="A2C",
+                    mode="validation", **ekw)])
+                val_obs = val_env.reset()
+                hl.drl_validation(model, val, val_env, val_obs)
+                sharpe = hl.get_validation_sharpe(63, "A2C")
+                last1 = hl.ensemble_prediction(rh._DummyVecEnv, mod.StockTradingEnv, model,
+                                               window(Tv, Tv + Tr), ekw, "ensemble", [], 126, thr, True)
+                last2 = hl.ensemble_prediction(rh._DummyVecEnv, mod.StockTradingEnv, model,
+                                               window(Tv + Tr, T), ekw, "ensemble", last1, 189, thr, False)
+            files = {}
+            for fn in sorted(os.listdir("results")):
+                if fn.endswith(".csv"):
+                    files[fn] = open(os.path.join("results", fn)).read()
+        finally:
+            os.chdir(cwd)
+        out.update(close=close, tech=tech, risk=risk, dates=np.asarray(dates),
+                   cfg_int=np.array([T, N, K, Tv, Tr, ekw["hmax"], int(thr is not None)], np.int64),
+                   cfg_float=np.array([ekw["initial_amount"], 1e-3, 1e-3, 1e-4,
+                                       thr if thr is not None else 0.0]),
+                   sharpe=np.array(sharpe), last_state_1=np.asarray(last1, np.float64),
+                   last_state_2=np.asarray(last2, np.float64),
+                   csv_names=np.asarray(list(files)), csv_texts=np.asarray(list(files.values())),
+                   model_steps=np.array(model.step, np.int64))
     elif kind == "erl_stocknp":
         mod = rh.load_stocktrading_np()
         price = 100 * np.exp(np.cumsum(rng.normal(0, 0.01, (T, N)), axis=0))
@@ -945,6 +998,10 @@ HARNESS_SCENARIOS = {
                                  sigma=0.05, patient=True),
     "erl_stocknp": dict(kind="erl_stocknp", seed=88, T=40, N=30, K=8),
     "stock_f64actions": dict(kind="stock_f64actions", seed=89, T=16, N=30, K=2),
+    "ensemble": dict(kind="ensemble", seed=90, T=25, N=6, K=3, Tv=9, Tr=8, initial_amount=30_000,
+                     turbulence_threshold=45.0, flag_frac=0.03),
+    "ensemble_dow30": dict(kind="ensemble", seed=91, T=30, N=30, K=8, Tv=10, Tr=10,
+                           initial_amount=200_000),
 }
 
 

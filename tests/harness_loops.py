@@ -6,6 +6,13 @@ the unmodified reference envs, so the fixtures pin the facade's harness surface 
   * ``drl_prediction``          <- finrl/agents/stablebaselines3/models.py:110-129
   * ``elegantrl_prediction``    <- finrl/agents/elegantrl/models.py:105-125 (torch tensors replaced
                                    by numpy: the agent network is not part of the env path)
+  * ``drl_validation`` / ``get_validation_sharpe`` / ``ensemble_prediction``
+                                <- models.py:272-276, :213-230, :278-325: the rolling-window
+                                   ensemble's use of the env (CSV dumps of the terminal branch read
+                                   back for the Sharpe ratio; ``render()`` -> ``last_state`` ->
+                                   ``initial=False, previous_state=last_state`` of the next window);
+                                   scalar costs (the fork's env raises on the lists the reference's
+                                   own ensemble passes, SURVEY.md headline 5)
 A trained policy is replaced by ``ScriptedModel`` / ``scripted_act``: deterministic functions of
 (step, observation) whose float32 arithmetic is exact, so both sides see identical actions only if
 the observations they return are identical.
@@ -55,6 +62,44 @@ def elegantrl_prediction(act, environment):
         if done:
             break
     return episode_total_assets, episode_returns
+
+
+def drl_validation(model, test_data, test_env, test_obs):
+    """models.py:272-276: one pass over the validation window (the env's terminal branch writes
+    results/account_value_validation_<model>_<iteration>.csv, env_stocktrading.py:266-292)."""
+    for _ in range(len(test_data.index.unique())):
+        action, _states = model.predict(test_obs)
+        test_obs, rewards, dones, info = test_env.step(action)
+
+
+def get_validation_sharpe(iteration, model_name):
+    """models.py:213-230."""
+    import pandas as pd
+    df_total_value = pd.read_csv(f"results/account_value_validation_{model_name}_{iteration}.csv")
+    if df_total_value["daily_return"].var() == 0:
+        return np.inf if df_total_value["daily_return"].mean() > 0 else 0.0
+    return (4 ** 0.5) * df_total_value["daily_return"].mean() / df_total_value["daily_return"].std()
+
+
+def ensemble_prediction(make_vec_env, env_cls, model, trade_data, env_kwargs, name, last_state,
+                        iter_num, turbulence_threshold, initial):
+    """models.py:278-325: trade one window through ``DummyVecEnv([lambda: StockTradingEnv(...)])``,
+    take ``render()`` on the second-to-last day as the state handed to the next window, dump it."""
+    import pandas as pd
+    trade_env = make_vec_env([lambda: env_cls(
+        df=trade_data, turbulence_threshold=turbulence_threshold, initial=initial,
+        previous_state=last_state, model_name=name, mode="trade", iteration=iter_num,
+        **env_kwargs)])
+    trade_obs = trade_env.reset()
+    n_days = len(trade_data.index.unique())
+    for i in range(n_days):
+        action, _states = model.predict(trade_obs)
+        trade_obs, rewards, dones, info = trade_env.step(action)
+        if i == (n_days - 2):
+            last_state = trade_env.render()
+    df_last_state = pd.DataFrame({"last_state": last_state})
+    df_last_state.to_csv(f"results/last_state_{name}_{i}.csv", index=False)
+    return last_state
 
 
 class ScriptedModel:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of library variants on ONE box: N = 100 bench line per variant, three rounds, interleaved
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-mkdir -p $ROOT/gpurun_out/r02
+mkdir -p $ROOT/gpurun_out/${RDIR:-r03}
 ARGS="${ARGS:---tickers 100 --turbulence-pct 90 --steps 2000 --warmup 500}"
 for round in 1 2 3; do
   for v in "$@"; do

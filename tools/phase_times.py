@@ -72,6 +72,23 @@ def main():
     sl = fin >= thr
     for k in (1, 2, 7, 9, 10):
         print(f"   slow blocks, trader stamp {k}: median {np.median(rel[:, :, 0, k][sl]):.2f}")
+    # blocks b and b + 8 share an XCD (round-robin dispatch): finish times per b % 8
+    bi = np.arange(nb) % 8
+    print("median finish per block index mod 8 (trader | streamer's last market-data store issued):")
+    print("   trader  ", " ".join(f"{np.median(rel[:, bi == x, 0, 11]):6.2f}" for x in range(8)))
+    print("   streamer", " ".join(f"{np.median(rel[:, bi == x, 1, 4]):6.2f}" for x in range(8)))
+    print("   trader loads back (stamp 1)", " ".join(f"{np.median(rel[:, bi == x, 0, 1]):6.2f}" for x in range(8)))
+    if NT == 100:       # the wide kernel also records where each wave ran (slot 13)
+        raw = (a[0, :, 0, 13] / 0.01).round().astype(np.int64)
+        xcc, hw = raw & 0xff, raw >> 8
+        cu, sh, se, simd = (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7, (hw >> 4) & 3
+        fin_b = np.median(rel[:, :, 0, 11], axis=0)
+        strm_b = np.median(rel[:, :, 1, 4], axis=0)
+        print("block % 8 -> XCC_ID:", [sorted(set(xcc[bi == x].tolist())) for x in range(8)])
+        for name, key in (("XCC", xcc), ("SE", se), ("SH", sh), ("CU", cu), ("SIMD", simd)):
+            ks = sorted(set(key.tolist()))
+            print(f"   median trader finish / streamer done by {name}:",
+                  " ".join(f"{k}:{np.median(fin_b[key == k]):.1f}/{np.median(strm_b[key == k]):.1f}" for k in ks))
     last = rel[:, :, 0, 11].max(axis=1)
     print(f"last trader finishes at {np.median(last):.2f} us; last streamer at "
           f"{np.median(rel[:, :, 1, 4].max(axis=1)):.2f} us")
