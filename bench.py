@@ -275,6 +275,7 @@ def build_workload(args, torch, dev, rank):
                 w.env.state["day"].copy_(offs)
                 w.env.state["price_day"].copy_(offs)
                 w.env.state["start_day"].copy_(offs)
+                w.env.refresh()         # price_day edited in place: re-evaluate the carried begin asset
                 w.env.hint_desynchronised(True)
             w.after_reset = _desync
     elif args.env == "portfolio":

@@ -185,6 +185,7 @@ def lib():
     L.finenv_stock_init.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     L.finenv_stock_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.finenv_stock_observe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.finenv_stock_refresh.argtypes = [C.c_void_p, C.c_void_p]
     L.finenv_stock_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.finenv_stock_episode_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

@@ -289,6 +289,16 @@ int finenv_stock_observe(finenv_stock *h, float *obs_out, void *stream)
     return check_launch(h, "stock_observe");
 }
 
+int finenv_stock_refresh(finenv_stock *h, void *stream)
+{
+    if (!h) return FINENV_ERR_INVALID;
+    if (!h->bound) return fail(h, FINENV_ERR_UNBOUND, "refresh: bind first%s");
+    const finenv_host::DeviceGuard guard(h->device);
+    Params p = make_params(h);
+    launch_aux(h, p, 3, (hipStream_t)stream);
+    return check_launch(h, "stock_refresh");
+}
+
 int finenv_stock_step(finenv_stock *h, const float *actions, float *obs, float *reward,
                       uint8_t *done, float *term_obs, int32_t *realised, int32_t auto_reset,
                       void *stream)

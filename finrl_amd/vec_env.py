@@ -26,6 +26,23 @@ def _torch():
     return torch
 
 
+def _checked_out_pitch(out, obs, reward, done):
+    """Validate step(out=(obs, reward, done)) against the env's own output tensors and return the row
+    pitch (floats) of out[0].  The kernel writes float32 rows of D columns `pitch` floats apart."""
+    o, r, d = out
+    E, D = obs.shape
+    for t, ref, what in ((o, obs, "out[0]"), (r, reward, "out[1]"), (d, done, "out[2]")):
+        if t.dtype != ref.dtype or t.device != ref.device or tuple(t.shape) != tuple(ref.shape):
+            raise ValueError(f"{what} must be {tuple(ref.shape)} {ref.dtype} on {ref.device}")
+    if o.stride(-1) != 1 or not r.is_contiguous() or not d.is_contiguous():
+        raise ValueError("out[0] needs unit column stride; out[1] / out[2] must be contiguous")
+    if E == 1:                  # (torch reports an arbitrary row stride for a single row)
+        return D
+    if o.stride(0) < D:
+        raise ValueError("out[0]: rows overlap (row stride smaller than the observation dimension)")
+    return o.stride(0)
+
+
 class VecStockTradingEnv:
     """E parallel copies of the reference ``StockTradingEnv`` (env_stocktrading.py:19-552).
 
@@ -183,6 +200,12 @@ class VecStockTradingEnv:
                                        self._stream()), self._h, "reset")
         return self.obs
 
+    def refresh(self):
+        """Call after editing ``state["cash"]`` / ``state["holdings"]`` / ``state["price_day"]`` in
+        place: re-evaluates the carried begin asset (``state["begin_asset"]``) that ``step`` uses
+        for the next reward instead of recomputing it (finenv_stock_refresh)."""
+        nat.check(nat.lib().finenv_stock_refresh(self._h, self._stream()), self._h, "refresh")
+
     def observe(self):
         """render() (:395-396): current observation without stepping."""
         self._use_pitch(self._pitch)
@@ -218,9 +241,7 @@ class VecStockTradingEnv:
         ret = (self.obs, self.reward, self.done)
         if out is not None:
             ret = out
-            if out[0].stride(-1) != 1 or tuple(out[0].shape) != tuple(self.obs.shape):
-                raise ValueError("out[0] must be [E, D] float32 with unit column stride")
-            self._use_pitch(out[0].stride(0))
+            self._use_pitch(_checked_out_pitch(out, self.obs, self.reward, self.done))
             outs = (C.c_void_p(out[0].data_ptr()), C.c_void_p(out[1].data_ptr()),
                     C.c_void_p(out[2].data_ptr())) + outs[3:]
         elif self._pitch_set != self._pitch:

@@ -181,9 +181,11 @@ class VecStockTradingEnvNP:
                 actions.device != self.obs.device:
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
         obs, rew, done = out if out is not None else (self.obs, self.reward, self.done)
-        if obs.stride(-1) != 1 or tuple(obs.shape) != tuple(self.obs.shape):
-            raise ValueError("out[0] must be [E, D] float32 with unit column stride")
-        self._use_pitch(obs.stride(0))
+        if out is not None:
+            from .vec_env import _checked_out_pitch
+            self._use_pitch(_checked_out_pitch(out, self.obs, self.reward, self.done))
+        else:
+            self._use_pitch(self._pitch)
         nat.check(nat.lib().finenv_stocknp_step(
             self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(obs.data_ptr()),
             C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()),

@@ -186,6 +186,14 @@ int finenv_stock_reset(finenv_stock *h, const uint8_t *mask, float *obs_out, voi
 /* render() / current state (:395-396): writes obs [E][D] without changing state. */
 int finenv_stock_observe(finenv_stock *h, float *obs_out, void *stream);
 
+/* After the CALLER has edited cash, holdings or price_day of the bound state block in place
+ * (restoring a snapshot, desynchronising a batch): re-evaluate FINENV_SF_BEGIN_ASSET = cash +
+ * sum(close[price_day] * holdings) in the reference's order (:311-314).  step() carries that field
+ * from one step's end asset to the next step's begin asset and never recomputes it; init / reset
+ * write it themselves.  Without this call the first reward after such an edit is computed against
+ * a stale begin asset. */
+int finenv_stock_refresh(finenv_stock *h, void *stream);
+
 /* step() (:220-357) for all envs in ONE launch.
  *   actions   [E][N] f32 in [-1, 1]
  *   obs       [E][D] f32 (next observation; after auto-reset: the reset observation)

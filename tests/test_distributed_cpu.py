@@ -51,6 +51,45 @@ def _worker(rank, world, port, global_envs, q):
     dist.destroy_process_group()
 
 
+def _worker_missing_global(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(7, rank, world)                 # ragged shards: 4 + 3
+    local = torch.arange(lo, hi, dtype=torch.float32)
+    res = []
+    try:
+        gather_episode_returns(local)                    # size of the collective unknowable locally
+        res.append("no error")
+    except ValueError as ex:
+        res.append(str(ex))
+    try:                                                  # a shard of the wrong size raises before
+        gather_episode_returns(local[:1], 7)              # the collective (on every rank here)
+        res.append("no error")
+    except ValueError as ex:
+        res.append(str(ex))
+    out = gather_episode_returns(local, 7)                # and the ranks are still in step
+    q.put((rank, res, out.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_requires_global_envs_when_sharded():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_missing_global, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, msgs, out in res:
+        assert "global_envs is required" in msgs[0] and "holds 1 envs" in msgs[1]
+        np.testing.assert_array_equal(out, np.arange(7, dtype=np.float32))
+
+
 @pytest.mark.parametrize("world,global_envs", [(2, 256), (2, 7), (3, 10)])
 def test_gather_episode_returns_gloo(world, global_envs):
     ctx = mp.get_context("spawn")

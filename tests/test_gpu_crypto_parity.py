@@ -314,3 +314,31 @@ def test_crypto_masked_reset_desynchronises_envs(cfg):
             saw_partial_done |= not o_done.all()
             np.testing.assert_array_equal(env.term_obs.cpu().numpy()[o_done], o_term[o_done])
     assert saw_partial_done and len(np.unique(orc.state()["time"])) > 1
+
+
+def test_rollout_step_takes_any_policy_output_placement():
+    """RolloutBuffer.step with policy outputs the one-launch form cannot take (host tensors, float64,
+    a transposed view) and E % 4 == 0: falls back to put() + step() instead of handing a host
+    pointer to the kernel; results equal the all-device path."""
+    _need_gpu()
+    from finrl_amd.rollout import RolloutBuffer
+    from finrl_amd.vec_crypto import VecCryptoEnv
+    rng = np.random.default_rng(12)
+    T, N, W, E = 20, 10, 40, 256
+    price, tech = _crypto_panel(rng, T, N, W)
+    a_env = VecCryptoEnv({"price_array": price, "tech_array": tech}, E)
+    b_env = VecCryptoEnv({"price_array": price, "tech_array": tech}, E)
+    buf_a, buf_b = RolloutBuffer(4, E, a_env.obs_dim, N), RolloutBuffer(4, E, b_env.obs_dim, N)
+    a_env.reset(); b_env.reset()
+    for t in range(4):
+        a = torch.rand(E, N) * 2 - 1
+        v, lp = torch.randn(E), torch.randn(E)
+        forms = [(a, v, lp),                                               # host tensors
+                 (a.cuda(), v.double().cuda(), lp.cuda()),                 # float64 values
+                 (a.cuda().t().contiguous().t(), v.cuda(), lp.cuda()),     # non-contiguous actions
+                 (a.cuda(), v.cuda(), lp)][t]                              # one host tensor
+        buf_a.step(a_env, t, *forms)
+        buf_b.step(b_env, t, a.cuda(), v.cuda(), lp.cuda())
+        for k in ("actions", "values", "log_probs", "rewards", "dones"):
+            assert torch.equal(getattr(buf_a, k)[t], getattr(buf_b, k)[t]), (k, t)
+        assert torch.equal(buf_a.obs[t + 1], buf_b.obs[t + 1])
