@@ -201,7 +201,10 @@ def side_traffic(kind, E):
     """PMC-measured HBM bytes per launch of a sibling kernel (profiles/side_traffic.json), or None."""
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "side_traffic.json")))
-        if tj.get("envs_per_gpu") == E:
+        for rec in tj.get("records", []):              # one record per (env, batch size) profiled
+            if rec.get("env") == kind and rec.get("envs_per_gpu") == E:
+                return rec["hbm_bytes_per_launch"]
+        if tj.get("envs_per_gpu") == E and kind in tj.get("envs", {}):
             return tj["envs"][kind]["hbm_bytes_per_launch"]
     except Exception:
         pass
@@ -686,8 +689,17 @@ def main(argv=None):
             "config": dict({"workload": work.workload, "envs_per_gpu": E,
                             "global_envs": world * E, "parallelism": f"env-shard x{world}"},
                            **work.config_extra),
+            # frac: ALGORITHMIC bytes (bytes_formula x envs) / HIP-event launch time / 8 TB/s.
+            # hbm_frac: the bytes the HBM counters saw for this kernel and shape (traffic: rocprofv3
+            # PMC passes committed under profiles/, null when that shape was not profiled) over the
+            # same time -- below frac where the formula charges rows that L2 / Infinity Cache serve,
+            # above it where bookkeeping state and partial-segment writes add traffic.
+            # wall_frac: frac with the host clock's ms_per_step instead of the HIP events.
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": work.traffic,
+                         "hbm_frac": (work.traffic / per_launch_s / 1e9 / HBM_PEAK_GBS
+                                      if work.traffic else None),
+                         "wall_frac": work.B * E / (wall / args.steps) / 1e9 / HBM_PEAK_GBS,
                          "kernel": work.kernel, "bytes_per_env_step": work.B,
                          "bytes_formula": work.B_note, "avg_launch_us": per_launch_s * 1e6},
         }

@@ -84,22 +84,6 @@ struct CrParams {
 #define CI(fld) (*at(p.st.i32, (unsigned)(fld) * (unsigned)E + (unsigned)e))
 #define STK(i) (*at(p.st.stocks, (unsigned)(i) * (unsigned)E + (unsigned)e))
 
-__device__ __forceinline__ double cr_floordiv(double a, double d)   // exact floor(a/d), d > 0
-{
-    double x = __builtin_amdgcn_rcp(d);
-    x = fma(fma(-d, x, 1.0), x, x);
-    double q = floor(a * x);
-    double r = fma(-q, d, a);
-    // estimate within 1 of the true floor for |a/d| < 2^40; two fix-up rounds for safety
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const double adj = (r < 0.0) ? -1.0 : ((r >= d) ? 1.0 : 0.0);
-        q += adj;
-        r = fma(-q, d, a);
-    }
-    return q;
-}
-
 // rows[el*stride + 0] = f32(cash * 2^-18), rows[el*stride + 1 + i] = stocks_i * 2^-3   (:93)
 // columns >= 1 + N: tech_scaled[(t_el - l) * W + j]                              (:94-97)
 __device__ __forceinline__ void cr_write_rows(float *__restrict__ dst, const CrParams &p,
@@ -334,14 +318,13 @@ __global__ void __launch_bounds__(kWave *(TWO ? 2 * kWaves : kWaves), 1) crypto_
         const float a = act[i];
         const double pr = prc[i];
         const bool ok = a > 0.0f && pr > 0.0;
-        double q = floor(cash * xr[i]);                                       // cash // price
-        double r = fma(-q, pr, cash);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {     // estimate within 1 of the true floor; two rounds for safety
-            const double adj = (r < 0.0) ? -1.0 : ((r >= pr) ? 1.0 : 0.0);
-            q += adj;
-            r = fma(-q, pr, cash);
-        }
+        // cash // price.  x = refined reciprocal (relative error far below 2^-40), so floor(cash * x)
+        // is within 1 of the true floor whenever the quotient is below 2^40, and the EXACT sign of the
+        // FMA remainder says which way: one fix-up makes it the true floor.  Above 2^40 the quotient
+        // dwarfs any action and min() returns the action whatever the last units of q are.
+        double q = floor(cash * xr[i]);
+        const double r = fma(-q, pr, cash);
+        q += (r < 0.0) ? -1.0 : ((r >= pr) ? 1.0 : 0.0);
         const double buy = ((double)a < q) ? (double)a : q;                   // min(avail, a)
         const float s_new = (float)((double)sv[i] + buy);
         const double cash_new = cash - pr * buy * one_p_cb;

@@ -31,9 +31,8 @@ constexpr int kMaxN = FINENV_STOCKNP_MAX_TICKERS;
 constexpr int kRowA = kMaxN + 1;                       // action rows, stride 33
 constexpr int kRowH = 2 * kMaxN + 1;                   // obs heads [amount|stocks|cool], stride 65
 constexpr int kWaves = 4;
-constexpr int kHeadMax = (2 + 3 * kMaxN) / kWave + 1;  // observation chunks holding per-env columns
-// heads/actions + stocks + cool + price row + parked head-chunk template values
-constexpr int kLdsPerWave = kWave * kRowH + 2 * kMaxN * kWave + kMaxN + kHeadMax * kWave;
+// heads/actions + stocks + cool + price row
+constexpr int kLdsPerWave = kWave * kRowH + 2 * kMaxN * kWave + kMaxN;
 
 struct NpParams {
     finenv_stocknp_config cfg;
@@ -192,7 +191,12 @@ __device__ __forceinline__ float holdings_value(const float *scol, const float *
 // step launches carry a second set of kWaves "streamer" waves per block (role 1): done and the
 // panel row of the next observation depend only on the day counter (:106, :137), so the chunks
 // of the observation rows that hold no per-env value (4 of 6 at DOW30x8) are streamed from the
-// first microsecond on, beside the trade arithmetic, instead of after it.
+// first microsecond on, beside the trade arithmetic, instead of after it.  The streamer does
+// nothing else: the trader writes the chunks that hold amount / stocks / cool-downs for all 64
+// rows itself (16 bytes per lane: two rows per store at DOW30), with no hand-off barrier.
+// The trader issues EVERY global load it needs before the one block barrier that releases the
+// streamers' stores: the CU's memory pipeline serves requests in order, and loads queued behind
+// four streamers' stores came back after 6 us (profiles/r02_stocknp_phase_timeline.txt).
 template <bool RESET_ONLY>
 __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_kernel(const NpParams p)
 {
@@ -212,7 +216,6 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
     float *scol = stk + lane, *ccol = cdl + lane;
     float *head = heads + lane * kRowH;
     float *prow_lds = cdl + kMaxN * kWave;                 // [ticker] shared price row (lock-step days)
-    float *ldshead = prow_lds + kMaxN;                     // [chunk][lane] head-chunk template values
 
     // reset(): day 0, start state, total_asset = amount + (stocks*price[0]).sum()  (:80-101)
     auto do_reset = [&](Num &amount, Num &ta, Num &gr, Num &ita) {
@@ -282,68 +285,71 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
         NSTAMP(9);
         np_write_rows(p.obs, p, e0, nenv_w, rd, vm, heads, lane, kpatch);
         NSTAMP(10);
-        // hand-off: once the traders have published amount / stocks / cool-downs in LDS, this wave
-        // writes the upper half of the rows of the chunks that hold them (the trader the lower
-        // half).  Episode-end steps keep that write in the trader.
-        lds_barrier();
-        if (dm == 0ull && !NDIAG(1)) {
-            HeadPlan<kHeadMax> hp;
-            head_plan(hp, ldshead, p.D, rd, __builtin_amdgcn_readfirstlane(rd), vm, lane, kpatch,
-                      head_widx);
-            if (hp.uniform)
-                head_store(hp, p.obs, p.D, p.obs_pitch, e0, nenv_w, vm, lane, kWave / 2, kWave,
-                           [heads](int el, int w) { return heads[el * kRowH + w]; });
-            else
-                np_write_rows(p.obs, p, e0, nenv_w, rd, vm & 0xFFFFFFFF00000000ull, heads, lane, 0,
-                              kpatch);
-        }
         return;
     }
-    // ---- action tile -> LDS rows (stride kRowA inside the heads region) ---------------------
-    lds_barrier();                           // pairs with the streamers' barrier (see above)
-    stage_action_tile(heads, kRowA, p.actions + (size_t)e0 * N, nenv_w, N, p.magicN, lane);
+    // ---- trader: all global loads first -- the day counter (the second round trip hangs on it),
+    // scalars, stocks / cool-downs, the action tile (flat and coalesced) -- then the barrier that
+    // lets the streamers start storing, then the LDS images ---------------------------------------
+    const int day = NI(FINENV_NI_DAY) + 1;                                        // :106
     const int tags = NI(FINENV_NI_TAGS);
     Num amount = mk(NF(FINENV_NF_AMOUNT), tags & 3);
     const Num ta_old = mk(NF(FINENV_NF_TOTAL_ASSET), (tags >> 2) & 3);
     Num gr = mk(NF(FINENV_NF_GAMMA_REWARD), (tags >> 4) & 3);
     Num ita = mk(NF(FINENV_NF_INITIAL_TOTAL_ASSET), (tags >> 6) & 3);
-    const int day = NI(FINENV_NI_DAY) + 1;                                        // :106
+    float sv[kMaxN], cv[kMaxN], av[kMaxN];
+#pragma unroll
+    for (int i = 0; i < kMaxN; ++i) {
+        sv[i] = NS(0, min(i, N - 1));
+        cv[i] = NS(1, min(i, N - 1));
+    }
+    const int a_total = nenv_w * N;
+    const float *const a_src = p.actions + (size_t)e0 * N;
+#pragma unroll
+    for (int j = 0; j < kMaxN; ++j) {
+        const int f = j * kWave + lane;
+        av[j] = *at(a_src, (unsigned)(f < a_total ? f : a_total - 1));
+    }
     const unsigned pb = (unsigned)(day * N);
     const int day0 = __builtin_amdgcn_readfirstlane(day);
     const bool uni = __all(day == day0);                   // lock-step batch: one price row per wave
-    if (uni && lane < kMaxN)
-        prow_lds[lane] = *at(p.panel.price, (unsigned)(day0 * N + min(lane, N - 1)));
+    float prv = 0.0f;
+    if (uni && lane < kMaxN) prv = *at(p.panel.price, (unsigned)(day0 * N + min(lane, N - 1)));
     const float *prow = uni ? prow_lds : nullptr;
-    // market-data values of the head chunks of the NEXT observation (row `day`), fetched now --
-    // the trader has no stores in flight yet -- and parked in LDS before the hand-off barrier: a
-    // global load issued after the streamers' stores waits behind them (13 us measured here)
-    float head_tt[kHeadMax];
-    head_fetch(head_tt, p.panel.obs_tmpl, p.D, day0, lane, kpatch);
-    // (global loads in batches, issued before their first use: a rolled loop exposes one HBM round
-    //  trip per ticker at one wave per SIMD)
-    for (int i0 = 0; i0 < N; i0 += 16) {
-        float sv[16], cv[16];
+    // market-data values of the head chunks of the NEXT observation (row `day`), 16 bytes per lane:
+    // lane (sub, q) holds columns 4q .. 4q + 3 of the 64 * kpatch head columns
+    typedef float np_f4 __attribute__((ext_vector_type(4)));
+    typedef np_f4 np_f4u __attribute__((aligned(4)));
+    const int lpr = 16 * kpatch;                           // lanes per row in the quad form
+    const bool quad_ok = kpatch <= 2 && p.D >= kWave * kpatch;
+    np_f4 head_q = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (quad_ok)
+        head_q = *reinterpret_cast<const np_f4u *>(reinterpret_cast<const char *>(p.panel.obs_tmpl) +
+                                                   (size_t)((unsigned)(day0 * p.D + 4 * (lane & (lpr - 1))) * 4u));
+    const bool calm = *at(p.panel.turb_bool, (unsigned)day) == 0.0f;              // :110
+    // (releasing the streamers before the day-dependent loads above instead: 27.0 vs 26.65 us, same box)
+    lds_barrier();                           // pairs with the streamers' barrier (see above)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            sv[j] = NS(0, min(i0 + j, N - 1));
-            cv[j] = NS(1, min(i0 + j, N - 1));
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { pin(sv[j]); pin(cv[j]); }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (i0 + j >= N) break;
-            scol[(i0 + j) * kWave] = sv[j];
-            ccol[(i0 + j) * kWave] = cv[j] + 1.0f;                                // :108
+    for (int j = 0; j < kMaxN; ++j) {        // action tile -> rows of stride kRowA in the heads region
+        const int f = j * kWave + lane;
+        if (f < a_total) {
+            const int el = (N == 1) ? f : (int)__umulhi((unsigned)f, p.magicN);
+            heads[el * kRowA + (f - el * N)] = av[j];
         }
     }
+#pragma unroll
+    for (int i = 0; i < kMaxN; ++i) {
+        if (i >= N) continue;
+        cv[i] += 1.0f;                                                            // :108
+        scol[i * kWave] = sv[i];
+        ccol[i * kWave] = cv[i];
+    }
+    if (uni && lane < kMaxN) prow_lds[lane] = prv;
     wave_sync();
     NSTAMP(1);
     const float *arow = heads + lane * kRowA;
     const float ms = (float)p.cfg.max_stock;
     const Num one_m = mk(1 - p.cfg.sell_cost_pct, FINENV_NT_PY);
     const Num one_p = mk(1 + p.cfg.buy_cost_pct, FINENV_NT_PY);
-    const bool calm = *at(p.panel.turb_bool, (unsigned)day) == 0.0f;              // :110
     const int min_action = p.cfg.min_action;
 
     // sells then buys, ticker index order (:112-129); liquidation when turbulent (:131-134)
@@ -353,18 +359,18 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
     // trade loops run on plain doubles -- the per-operation dtype dispatch of Num (both roundings
     // computed, tag-selected) is most of this kernel's arithmetic; any other tag mix takes the
     // generic loops below.  Same operations, same order, same roundings in both.
+    bool head_filled = false;
     if (__all(amount.tag == FINENV_NT_F64)) {
         // Statically indexed registers, branch-free per ticker (selects), reciprocals of the prices
         // computed off the cash chain: the first form kept stocks / cool-downs / actions in LDS and
         // paid an LDS round trip inside every divergent per-ticker block (10.4 us of a 34 us step).
         double amt = amount.v;
-        float sr[kMaxN], cr[kMaxN], pr_[kMaxN];
+        float (&sr)[kMaxN] = sv, (&cr)[kMaxN] = cv;          // as loaded (cool-downs already + 1)
+        float pr_[kMaxN];
         int ai[kMaxN];
 #pragma unroll
         for (int i = 0; i < kMaxN; ++i) {
             const int ic = min(i, N - 1);
-            sr[i] = scol[ic * kWave];
-            cr[i] = ccol[ic * kWave];
             ai[i] = (int)(arow[ic] * ms);                                         // :104
             pr_[i] = 0.0f;
         }
@@ -407,13 +413,12 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
             const int a = ai[i];
             const double d = (double)pr_[i];
             const bool ok = calm && a > min_action && pr_[i] > 0.0f;
-            double q = floor(amt * xr[i]);                                        // amount // price
-            double r = fma(-q, d, amt);
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {     // (floordiv_true with the reciprocal hoisted)
-                q += (r < 0.0) ? -1.0 : ((r >= d) ? 1.0 : 0.0);
-                r = fma(-q, d, amt);
-            }
+            // amount // price (floordiv_true with the reciprocal hoisted).  floor(amt * x) is within 1
+            // of the true floor for quotients below 2^40 and the exact sign of the FMA remainder says
+            // which way: ONE fix-up round; above 2^40 min() returns the (int32) action regardless.
+            double q = floor(amt * xr[i]);
+            const double r = fma(-q, d, amt);
+            q += (r < 0.0) ? -1.0 : ((r >= d) ? 1.0 : 0.0);
             const double buy = ((double)a < q) ? (double)a : q;                   // min(q, a)
             const float s_new = (float)((double)sr[i] + buy);
             const double amt_new = amt - ((d * buy) * one_p.v);
@@ -421,13 +426,24 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
             cr[i] = ok ? 0.0f : cr[i];
             amt = ok ? amt_new : amt;
         }
+        amount = mk(amt, FINENV_NT_F64);
+        // books back to LDS and, in the same pass, this env's observation head (amount | stocks |
+        // cool-downs) over the consumed action rows -- every lane has read its own action row above
+        wave_sync();
+        {
+            const double fl = p.cfg.obs_amount_floor;
+            const Num shown = (fl > 0.0 && fl > amount.v) ? mk(fl, FINENV_NT_PY) : amount;
+            head[0] = (float)n_mul(shown, mk(0x1p-12, FINENV_NT_PY)).v;          // :150
+        }
 #pragma unroll
         for (int i = 0; i < kMaxN; ++i) {
             if (i >= N) continue;
             scol[i * kWave] = sr[i];
             ccol[i * kWave] = cr[i];
+            head[1 + i] = sr[i] * 0x1p-6f;
+            head[1 + N + i] = cr[i];
         }
-        amount = mk(amt, FINENV_NT_F64);
+        head_filled = calm;                  // (a turbulent day still liquidates below)
     } else {
         for (int i0 = 0; i0 < N; i0 += kPB) {
             float prb[kPB];
@@ -522,7 +538,7 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
     }
     NSTAMP(3);
     wave_sync();
-    fill_head(amount);                       // overwrites the (consumed) action rows
+    if (!head_filled) fill_head(amount);     // overwrites the (consumed) action rows
     wave_sync();
     const unsigned long long valid_mask = __ballot(valid);
     const unsigned long long done_mask = __ballot(done && valid);
@@ -541,18 +557,38 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
         }
     }
     NSTAMP(4);
-    head_park(ldshead, head_tt, lane);
-    lds_barrier();                           // hand-off: heads are final (pairs with the streamers')
+    // ---- the chunks holding amount / stocks / cool-downs, all rows.  Quad form (every env on the
+    // same row, nobody done): lane (sub, q) writes columns 4q .. 4q + 3 of row g * rpi + sub.
     if (!NDIAG(2)) {
-        HeadPlan<kHeadMax> hp;
-        head_plan(hp, ldshead, p.D, row_day, day0, valid_mask, lane, kpatch, head_widx);
-        if (done_mask == 0ull && hp.uniform)
-            head_store(hp, p.obs, p.D, p.obs_pitch, e0, nenv_w, valid_mask, lane, 0, kWave / 2,
-                       [heads](int el, int w) { return heads[el * kRowH + w]; });
-        else
-            np_write_rows(p.obs, p, e0, nenv_w, row_day,
-                          done_mask != 0ull ? valid_mask : (valid_mask & 0x00000000FFFFFFFFull),
-                          heads, lane, 0, kpatch);
+        const bool quad_rows = quad_ok && done_mask == 0ull && __all(!valid || row_day == day0);
+        if (quad_rows) {
+            const int rpi = kWave / lpr, sub = lane / lpr, q = lane & (lpr - 1);
+            int w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w[u] = head_widx(4 * q + u);
+            char *const hb = reinterpret_cast<char *>(p.obs + (size_t)e0 * p.obs_pitch);
+            constexpr int kB = 8;             // stores per batch: their LDS reads before their stores
+            for (int g0 = 0; g0 * rpi < nenv_w; g0 += kB) {
+                float pv4[kB][4];
+#pragma unroll
+                for (int j = 0; j < kB; ++j) {
+                    const int el = min((g0 + j) * rpi + sub, kWave - 1);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) pv4[j][u] = heads[el * kRowH + (w[u] >= 0 ? w[u] : 0)];
+                }
+#pragma unroll
+                for (int j = 0; j < kB; ++j) {
+                    const int el = (g0 + j) * rpi + sub;
+                    if (el >= nenv_w) continue;
+                    np_f4 v;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = w[u] >= 0 ? pv4[j][u] : head_q[u];
+                    *reinterpret_cast<np_f4u *>(hb + (size_t)((unsigned)(el * p.obs_pitch + 4 * q) * 4u)) = v;
+                }
+            }
+        } else {
+            np_write_rows(p.obs, p, e0, nenv_w, row_day, valid_mask, heads, lane, 0, kpatch);
+        }
     }
     NSTAMP(5);
     if (valid) store_state(amount, ta, gr, ita, r.tag, row_day);

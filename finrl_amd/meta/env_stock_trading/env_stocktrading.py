@@ -103,6 +103,7 @@ class StockTradingEnv:
             else 0
         self._asset0 = float(st["asset0"][0])
         self._last_reward = float(st["last_reward"][0])
+        self._begin_asset = float(st["begin_asset"][0])   # begin_total_asset of the NEXT step (:311-314)
         row = self._price_day
         self.state = ([self._cash] + self.panel.close[row].tolist() + self._shares.tolist()
                       + self.panel.tech[row].reshape(-1).tolist())
@@ -135,6 +136,7 @@ class StockTradingEnv:
         torch = self._torch
         a = torch.as_tensor(np.ascontiguousarray(self._device_actions(actions)))
         was_terminal_day = self.day >= self.panel.T - 1
+        begin_total_asset = self._begin_asset
         _, rew, done, _ = self._vec.step(a.to(self._vec.device))
         self.terminal = bool(done.cpu().numpy()[0])
         self._pull()
@@ -147,8 +149,7 @@ class StockTradingEnv:
         self.asset_memory.append(end_total_asset)
         self.date_memory.append(self._get_date())
         self.reward = self._last_reward                     # (end - begin) * reward_scaling
-        self.rewards_memory.append(self.reward / self.reward_scaling
-                                   if self.reward_scaling else 0.0)
+        self.rewards_memory.append(end_total_asset - begin_total_asset)      # unscaled, :350-351
         self.state_memory.append(self.state)
         return self.state, self.reward, self.terminal, {}
 

@@ -8,6 +8,11 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device visible: GPU tests must run on the MI355X box")
+
+
 @pytest.mark.parametrize("T", [1, 2, 3])
 @pytest.mark.parametrize("N", [1, 5, 32])
 def test_tiny_panels_match_oracle(T, N):
