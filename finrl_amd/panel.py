@@ -77,6 +77,26 @@ class StockPanel:
         return cls(close, tech, risk, tech_names=tech_indicator_list, dates=dates,
                    tickers=tickers)
 
+    # ------------------------------------------------------------------ .npz panel format
+    # the on-disk form of a packed panel.  Plain arrays only (loadable with
+    # numpy.load's default allow_pickle=False): close [T,N] f64, tech [T,K,N] f64, risk [T] f64,
+    # tech_names / dates / tickers as unicode arrays, format tag.
+    NPZ_FORMAT = "finrl_amd.StockPanel/1"
+
+    def save(self, path):
+        np.savez_compressed(path, format=np.array(self.NPZ_FORMAT), close=self.close, tech=self.tech,
+                            risk=self.risk, tech_names=np.asarray(self.tech_names, dtype=str),
+                            dates=np.asarray([str(d) for d in self.dates], dtype=str),
+                            tickers=np.asarray([str(t) for t in self.tickers], dtype=str))
+
+    @classmethod
+    def load(cls, path):
+        z = np.load(path, allow_pickle=False)
+        if str(z["format"]) != cls.NPZ_FORMAT:
+            raise ValueError(f"{path}: not a {cls.NPZ_FORMAT} file")
+        return cls(z["close"], z["tech"], z["risk"], tech_names=z["tech_names"].tolist(),
+                   dates=z["dates"].tolist(), tickers=z["tickers"].tolist())
+
     # ------------------------------------------------------------------ host packing
     def obs_template(self) -> np.ndarray:
         """f32 [T, D]: observation rows with cash / holdings slots left zero."""

@@ -84,3 +84,24 @@ def test_matches_reference_functions():
     fe = pre.FeatureEngineer(use_technical_indicator=False)
     pd.testing.assert_frame_equal(fe.clean_data(ragged), clean_data(ragged))
     assert clean_data(ragged).tic.nunique() == df.tic.nunique() - 2
+
+
+def test_panel_npz_round_trip(tmp_path):
+    """the .npz panel format -- plain arrays (no pickle), every field back bit for
+    bit, the packed device images of the reloaded panel equal the original's."""
+    from finrl_amd.panel import StockPanel
+    df = data_split(_frame(T=7, N=4, K=3).fillna(0).replace(np.inf, 0), "2020-01-01", "2020-01-08")
+    a = StockPanel.from_dataframe(df, ["ind0", "ind1", "ind2"], "turbulence")
+    path = os.path.join(tmp_path, "panel.npz")
+    a.save(path)
+    with np.load(path, allow_pickle=False) as z:           # plain arrays only
+        assert str(z["format"]) == StockPanel.NPZ_FORMAT and z["close"].dtype == np.float64
+    b = StockPanel.load(path)
+    for k in ("close", "tech", "risk"):
+        np.testing.assert_array_equal(getattr(a, k), getattr(b, k))
+    assert (a.tech_names, a.dates, a.tickers) == (b.tech_names, b.dates, b.tickers)
+    np.testing.assert_array_equal(a.obs_template(), b.obs_template())
+    np.testing.assert_array_equal(a.signed_close(), b.signed_close())
+    np.savez(os.path.join(tmp_path, "other.npz"), format=np.array("something else"), close=a.close)
+    with pytest.raises(ValueError):
+        StockPanel.load(os.path.join(tmp_path, "other.npz"))

@@ -130,3 +130,4 @@ def test_step_out_tensors_are_validated():
         npenv.step(torch.zeros(4, N, device="cuda"),
                    out=(torch.zeros(4, npenv.obs.shape[1], dtype=torch.float64, device="cuda"),
                         npenv.reward, npenv.done))
+

@@ -19,6 +19,7 @@ $P $O/crypto_256k "crypto_kernel<false" --env crypto --envs-per-gpu 262144
 $P $O/stocknp "stocknp_kernel<false" --env stocknp
 $P $O/cashpenalty "cashpenalty_kernel<false" --env cashpenalty
 $P $O/stoploss stoploss_step --env stoploss
+mkdir -p $O/drivercmd
 echo "--- driver command under the kernel trace"
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/drivercmd/trace -- python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/drivercmd/trace.log 2>&1 ) ; mkdir -p $O/drivercmd
 python3 tools/prof_summary.py $O/drivercmd stock_step > $O/drivercmd/summary.json

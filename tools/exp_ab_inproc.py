@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""A/B of two builds of libfinenv.so inside ONE process on ONE env: same handle, same device buffers
+(so the same physical placement), only the library that launches the step kernel alternates.
+usage: python3 tools/exp_ab_inproc.py <variant .so> <n100|n30|portfolio|stocknp> [rounds]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("FINENV_OBS_PLACEMENT", "first")
+sys.path.insert(0, ROOT)
+
+
+def main():
+    variants, kind = sys.argv[1].split(","), sys.argv[2]
+    rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    import torch
+    import bench
+    from finrl_amd import _native as nat
+    base_path = nat.LIB_PATH
+    libs = {}
+    for name, path in [("base", base_path)] + [(os.path.basename(v)[10:-3], os.path.abspath(v)) for v in variants]:
+        nat._lib, nat.LIB_PATH = None, path
+        libs[name] = nat.lib()
+    nat._lib, nat.LIB_PATH = libs["base"], base_path
+    dev = torch.device("cuda", 0)
+    a = dict(env="portfolio", tickers=30, turbulence_pct=None) if kind == "portfolio" else \
+        dict(env="stocknp", tickers=30, turbulence_pct=None) if kind == "stocknp" else \
+        dict(env="stock", tickers=100 if kind == "n100" else 30, turbulence_pct=90.0 if kind == "n100" else None)
+    args = type("A", (), dict(envs_per_gpu=65536, action_pool=8, rollout=0, desync=False, no_stats=False, **a))()
+    w = bench.build_workload(args, torch, dev, 0)
+    env = w.env
+    env.reset()
+    for i in range(2000):
+        env.step(w.pool[i % 8])
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        for name in libs:
+            nat._lib = libs[name]
+            if hasattr(env, "_step_args"):
+                env._step_args = None            # cached function pointer of the previous library
+            for i in range(100):
+                env.step(w.pool[i % 8])
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(500):
+                env.step(w.pool[i % 8])
+            e1.record()
+            torch.cuda.synchronize()
+            print(f"{kind} round {r} {name:8s} {e0.elapsed_time(e1) * 1e3 / 500:.2f} us", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -85,6 +85,31 @@ def main():
         fin_b = np.median(rel[:, :, 0, 11], axis=0)
         strm_b = np.median(rel[:, :, 1, 4], axis=0)
         print("block % 8 -> XCC_ID:", [sorted(set(xcc[bi == x].tolist())) for x in range(8)])
+        # which SIMDs the traders / streamers of one CU sit on (two waves per SIMD are resident per CU)
+        raw_s = (a[0, :, 1, 13] / 0.01).round().astype(np.int64)
+        simd_s = ((raw_s >> 8) >> 4) & 3
+        from collections import Counter
+        cu_key = xcc * 1000 + se * 100 + sh * 50 + cu
+        pat_t, pat_s, same = Counter(), Counter(), 0
+        for key in set(cu_key.tolist()):
+            m = cu_key == key
+            pat_t[tuple(sorted(simd[m].tolist()))] += 1
+            pat_s[tuple(sorted(simd_s[m].tolist()))] += 1
+        same = int((simd == simd_s).sum())
+        print("traders per CU, their SIMD ids (sorted) -> number of CUs:", dict(pat_t.most_common(8)))
+        print("streamers per CU, their SIMD ids -> number of CUs:", dict(pat_s.most_common(8)))
+        print(f"blocks whose trader and streamer share a SIMD: {same} of {nb}")
+        # traders that share their SIMD with another trader vs those that do not
+        shared = np.zeros(nb, bool)
+        for key in set(cu_key.tolist()):
+            idx = np.flatnonzero(cu_key == key)
+            c = Counter(simd[idx].tolist())
+            for i in idx:
+                shared[i] = c[simd[i]] > 1
+        if shared.any() and (~shared).any():
+            for k in (5, 7, 9, 11):
+                print(f"   trader stamp {k}: shares its SIMD with another trader {np.median(rel[:, shared, 0, k]):.2f} us "
+                      f"({int(shared.sum())} blocks), does not {np.median(rel[:, ~shared, 0, k]):.2f} us")
         for name, key in (("XCC", xcc), ("SE", se), ("SH", sh), ("CU", cu), ("SIMD", simd)):
             ks = sorted(set(key.tolist()))
             print(f"   median trader finish / streamer done by {name}:",
