@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -525,7 +526,10 @@ void cr_launch_np(const CrParams &p, hipStream_t stream)
     CrParams q = p;
     const int n4 = p.rec_na4 + 2 * p.rec_nv4;            // record work (0: plain step)
     const size_t lds1 = sizeof(float) * lds_per_wave(NP);
-    if (waves <= kSmallWaves) {
+    // (regime boundary checked in one process, same buffers: with streamers 9.05 / 11.0 / 12.7 us at
+    //  65,536 / 98,304 / 131,072 envs, without 10.0 / 12.5 / 13.0 us)
+    const int small_waves = kSmallWaves;
+    if (waves <= small_waves) {
         const int rec_blocks = n4 > 0 ? min(512, (n4 + kWave * 16 - 1) / (kWave * 16)) : 0;
         q.env_blocks = n4 > 0 ? waves : 0;
         if (RESET_ONLY)

@@ -191,9 +191,13 @@ __device__ __forceinline__ float holdings_value(const float *scol, const float *
 // step launches carry a second set of kWaves "streamer" waves per block (role 1): done and the
 // panel row of the next observation depend only on the day counter (:106, :137), so the chunks
 // of the observation rows that hold no per-env value (4 of 6 at DOW30x8) are streamed from the
-// first microsecond on, beside the trade arithmetic, instead of after it.  The streamer does
-// nothing else: the trader writes the chunks that hold amount / stocks / cool-downs for all 64
-// rows itself (16 bytes per lane: two rows per store at DOW30), with no hand-off barrier.
+// first microsecond on, beside the trade arithmetic, instead of after it -- 16 bytes per lane, one
+// store per row and 256 columns: this wave is slot-bound (a wave keeps 64 vector-memory operations in
+// flight, ~60 ns each under load), and four dword stores per row kept it busy for 17 us, longer
+// than the trader's whole chain.  Done after ~11 us, it waits at the hand-off barrier for the trader's
+// results and then writes the upper half of the rows of the chunks that hold amount / stocks /
+// cool-downs (16 bytes per lane: two rows per store at DOW30) and of the books; the trader the
+// lower halves and the scalars.
 // The trader issues EVERY global load it needs before the one block barrier that releases the
 // streamers' stores: the CU's memory pipeline serves requests in order, and loads queued behind
 // four streamers' stores came back after 6 us (profiles/r02_stocknp_phase_timeline.txt).
@@ -239,17 +243,22 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
             head[1 + N + i] = ccol[i * kWave];
         }
     };
-    auto store_state = [&](Num amount, Num ta, Num gr, Num ita, int rtag, int day) {
+    // the books (stocks, cool-downs) of tickers [i_lo, i_hi) from LDS back to the state block
+    auto store_books = [&](int i_lo, int i_hi) {
+        for (int i = i_lo; i < i_hi; ++i) {
+            NS(0, i) = scol[i * kWave];
+            NS(1, i) = ccol[i * kWave];
+        }
+    };
+    auto store_state = [&](Num amount, Num ta, Num gr, Num ita, int rtag, int day, int i_lo = 0,
+                           int i_hi = 1 << 30) {
         NF(FINENV_NF_AMOUNT) = amount.v;
         NF(FINENV_NF_TOTAL_ASSET) = ta.v;
         NF(FINENV_NF_GAMMA_REWARD) = gr.v;
         NF(FINENV_NF_INITIAL_TOTAL_ASSET) = ita.v;
         NI(FINENV_NI_TAGS) = amount.tag | (ta.tag << 2) | (gr.tag << 4) | (ita.tag << 6) | (rtag << 8);
         NI(FINENV_NI_DAY) = day;
-        for (int i = 0; i < N; ++i) {
-            NS(0, i) = scol[i * kWave];
-            NS(1, i) = ccol[i * kWave];
-        }
+        store_books(i_lo, min(i_hi, N));
     };
 
     if (RESET_ONLY) {
@@ -270,6 +279,44 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
         const int hidx = col - 3 - N;
         return col == 0 ? 0 : ((hidx >= 0 && hidx < 2 * N) ? 1 + hidx : -1);
     };
+    // ---- the chunks that hold amount / stocks / cool-downs, quad form: 16 bytes per lane, lane (sub, q)
+    // writes columns 4q .. 4q + 3 of row g * rpi + sub (two rows per store at DOW30); per-env values
+    // from the heads in LDS, market-data values from the quad `hq` every lane loaded for its columns
+    typedef float np_f4 __attribute__((ext_vector_type(4)));
+    typedef np_f4 np_f4u __attribute__((aligned(4)));
+    const int lpr = 16 * kpatch;                           // lanes per row
+    const bool quad_ok = kpatch <= 2 && p.D >= kWave * kpatch;
+    auto head_quads = [&](const np_f4 hq, int el_lo, int el_hi) {
+        const int rpi = kWave / lpr, sub = lane / lpr, q = lane & (lpr - 1);
+        int w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = head_widx(4 * q + u);
+        char *const hb = reinterpret_cast<char *>(p.obs + (size_t)e0 * p.obs_pitch);
+        constexpr int kB = 8;                 // stores per batch: their LDS reads before their stores
+        const int hi = min(nenv_w, el_hi);
+        for (int g0 = el_lo / rpi; g0 * rpi < hi; g0 += kB) {
+            float pv4[kB][4];
+#pragma unroll
+            for (int j = 0; j < kB; ++j) {
+                const int el = min((g0 + j) * rpi + sub, kWave - 1);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pv4[j][u] = heads[el * kRowH + (w[u] >= 0 ? w[u] : 0)];
+            }
+#pragma unroll
+            for (int j = 0; j < kB; ++j) {
+                const int el = (g0 + j) * rpi + sub;
+                if (el >= hi) continue;
+                np_f4 v;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = w[u] >= 0 ? pv4[j][u] : hq[u];
+                *reinterpret_cast<np_f4u *>(hb + (size_t)((unsigned)(el * p.obs_pitch + 4 * q) * 4u)) = v;
+            }
+        }
+    };
+    auto head_quad_load = [&](int row) -> np_f4 {
+        return *reinterpret_cast<const np_f4u *>(reinterpret_cast<const char *>(p.panel.obs_tmpl) +
+                                                 (size_t)((unsigned)(row * p.D + 4 * (lane & (lpr - 1))) * 4u));
+    };
     if (role == 0) NSTAMP(0);
     if (role == 1) {
         int day_s = NI(FINENV_NI_DAY) + 1;
@@ -282,9 +329,40 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
         if (dm != 0ull && p.term_obs != nullptr)
             np_write_rows<true>(p.term_obs, p, e0, nenv_w, day_s, dm, heads, lane, kpatch);
         const int rd = (done_s && p.auto_reset) ? 0 : day_s;
+        const int rd0 = __builtin_amdgcn_readfirstlane(rd);
+        const bool same_row = __all(!valid || rd == rd0);
+        // what follows the streaming is decided from the day counters alone, identically in the trader
+        const bool share = quad_ok && dm == 0ull && same_row;
+        np_f4 hq = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (share) hq = head_quad_load(rd0);           // (a load behind the stores below would wait for them)
         NSTAMP(9);
-        np_write_rows(p.obs, p, e0, nenv_w, rd, vm, heads, lane, kpatch);
+        // market-data chunks.  Every env of the wave on the same panel row: 16 bytes per lane, ONE store per
+        // row and 256 columns, the last quad shifted back to end at D (this wave is slot-bound: four dword
+        // stores per row took 17 us for 67 MB, same process / same buffers 26.6 -> 24.4 us per step)
+        const int c0 = kpatch * kWave, span = p.D - c0;
+        if (same_row && span >= 4) {
+            const int nq = (span + 3) >> 2;
+            char *const ob = reinterpret_cast<char *>(p.obs + (size_t)e0 * p.obs_pitch);
+            for (int q0 = 0; q0 < nq; q0 += kWave) {
+                const bool qa = q0 + lane < nq;
+                const int start = qa ? min(c0 + 4 * (q0 + lane), p.D - 4) : c0;
+                const np_f4 t = *reinterpret_cast<const np_f4u *>(
+                    reinterpret_cast<const char *>(p.panel.obs_tmpl) + (size_t)((unsigned)(rd0 * p.D + start) * 4u));
+#pragma unroll 4
+                for (int el = 0; el < nenv_w; ++el)
+                    if (qa) *reinterpret_cast<np_f4u *>(ob + (size_t)((unsigned)(el * p.obs_pitch + start) * 4u)) = t;
+            }
+        } else {
+            np_write_rows(p.obs, p, e0, nenv_w, rd, vm, heads, lane, kpatch);
+        }
         NSTAMP(10);
+        // hand-off: this wave is done ~3 us before the trader has its results; once they are final in LDS it
+        // takes the upper half of the head rows and of the books (the trader the lower halves and the scalars)
+        lds_barrier();                                                        // #2
+        if (share && !NDIAG(1)) {
+            head_quads(hq, kWave / 2, kWave);
+            if (valid) store_books(N / 2, N);
+        }
         return;
     }
     // ---- trader: all global loads first -- the day counter (the second round trip hangs on it),
@@ -302,6 +380,8 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
         sv[i] = NS(0, min(i, N - 1));
         cv[i] = NS(1, min(i, N - 1));
     }
+    // (the action tile staged by the idle streamer instead: 25.5 vs 24.4 us -- staging is the 23.6 MB of
+    //  reads at the chip's rate whichever wave issues them, and the streamer then starts 2 us later)
     const int a_total = nenv_w * N;
     const float *const a_src = p.actions + (size_t)e0 * N;
 #pragma unroll
@@ -317,14 +397,8 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
     const float *prow = uni ? prow_lds : nullptr;
     // market-data values of the head chunks of the NEXT observation (row `day`), 16 bytes per lane:
     // lane (sub, q) holds columns 4q .. 4q + 3 of the 64 * kpatch head columns
-    typedef float np_f4 __attribute__((ext_vector_type(4)));
-    typedef np_f4 np_f4u __attribute__((aligned(4)));
-    const int lpr = 16 * kpatch;                           // lanes per row in the quad form
-    const bool quad_ok = kpatch <= 2 && p.D >= kWave * kpatch;
     np_f4 head_q = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (quad_ok)
-        head_q = *reinterpret_cast<const np_f4u *>(reinterpret_cast<const char *>(p.panel.obs_tmpl) +
-                                                   (size_t)((unsigned)(day0 * p.D + 4 * (lane & (lpr - 1))) * 4u));
+    if (quad_ok) head_q = head_quad_load(day0);
     const bool calm = *at(p.panel.turb_bool, (unsigned)day) == 0.0f;              // :110
     // (releasing the streamers before the day-dependent loads above instead: 27.0 vs 26.65 us, same box)
     lds_barrier();                           // pairs with the streamers' barrier (see above)
@@ -557,41 +631,17 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
         }
     }
     NSTAMP(4);
-    // ---- the chunks holding amount / stocks / cool-downs, all rows.  Quad form (every env on the
-    // same row, nobody done): lane (sub, q) writes columns 4q .. 4q + 3 of row g * rpi + sub.
+    // ---- hand-off (pairs with the streamers' second barrier): heads and books are final in LDS.  With
+    // every env on the same row and nobody done, the streamer -- long finished -- writes the upper half of
+    // the head rows and of the books; otherwise this wave writes everything.
+    const bool share = quad_ok && done_mask == 0ull && __all(!valid || row_day == day0);
+    lds_barrier();                                                            // #2
     if (!NDIAG(2)) {
-        const bool quad_rows = quad_ok && done_mask == 0ull && __all(!valid || row_day == day0);
-        if (quad_rows) {
-            const int rpi = kWave / lpr, sub = lane / lpr, q = lane & (lpr - 1);
-            int w[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) w[u] = head_widx(4 * q + u);
-            char *const hb = reinterpret_cast<char *>(p.obs + (size_t)e0 * p.obs_pitch);
-            constexpr int kB = 8;             // stores per batch: their LDS reads before their stores
-            for (int g0 = 0; g0 * rpi < nenv_w; g0 += kB) {
-                float pv4[kB][4];
-#pragma unroll
-                for (int j = 0; j < kB; ++j) {
-                    const int el = min((g0 + j) * rpi + sub, kWave - 1);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) pv4[j][u] = heads[el * kRowH + (w[u] >= 0 ? w[u] : 0)];
-                }
-#pragma unroll
-                for (int j = 0; j < kB; ++j) {
-                    const int el = (g0 + j) * rpi + sub;
-                    if (el >= nenv_w) continue;
-                    np_f4 v;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] = w[u] >= 0 ? pv4[j][u] : head_q[u];
-                    *reinterpret_cast<np_f4u *>(hb + (size_t)((unsigned)(el * p.obs_pitch + 4 * q) * 4u)) = v;
-                }
-            }
-        } else {
-            np_write_rows(p.obs, p, e0, nenv_w, row_day, valid_mask, heads, lane, 0, kpatch);
-        }
+        if (share) head_quads(head_q, 0, kWave / 2);
+        else np_write_rows(p.obs, p, e0, nenv_w, row_day, valid_mask, heads, lane, 0, kpatch);
     }
     NSTAMP(5);
-    if (valid) store_state(amount, ta, gr, ita, r.tag, row_day);
+    if (valid) store_state(amount, ta, gr, ita, r.tag, row_day, 0, share ? N / 2 : N);
     NSTAMP(6);
 }
 

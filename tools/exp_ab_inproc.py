@@ -18,15 +18,25 @@ def main():
     from finrl_amd import _native as nat
     base_path = nat.LIB_PATH
     libs = {}
-    for name, path in [("base", base_path)] + [(os.path.basename(v)[10:-3], os.path.abspath(v)) for v in variants]:
-        nat._lib, nat.LIB_PATH = None, path
-        libs[name] = nat.lib()
+    envs = {}
+    for name, path in [("base", base_path)] + [(os.path.basename(v), v) for v in variants]:
+        setting = None
+        if "@" in path:                      # "<lib.so>@VAR=value": same library, an environment setting per run
+            path, setting = path.split("@", 1)
+        nat._lib, nat.LIB_PATH = None, os.path.abspath(path)
+        key = name if name == "base" else name[10:].replace(".so", "")
+        libs[key] = nat.lib()
+        envs[key] = setting
     nat._lib, nat.LIB_PATH = libs["base"], base_path
     dev = torch.device("cuda", 0)
-    a = dict(env="portfolio", tickers=30, turbulence_pct=None) if kind == "portfolio" else \
+    E = 65536
+    if kind.startswith("crypto"):          # crypto32768 / crypto65536 / crypto131072 / crypto262144
+        E = int(kind[6:])
+    a = dict(env="crypto", tickers=30, turbulence_pct=None) if kind.startswith("crypto") else \
+        dict(env="portfolio", tickers=30, turbulence_pct=None) if kind == "portfolio" else \
         dict(env="stocknp", tickers=30, turbulence_pct=None) if kind == "stocknp" else \
         dict(env="stock", tickers=100 if kind == "n100" else 30, turbulence_pct=90.0 if kind == "n100" else None)
-    args = type("A", (), dict(envs_per_gpu=65536, action_pool=8, rollout=0, desync=False, no_stats=False, **a))()
+    args = type("A", (), dict(envs_per_gpu=E, action_pool=8, rollout=0, desync=False, no_stats=False, **a))()
     w = bench.build_workload(args, torch, dev, 0)
     env = w.env
     env.reset()
@@ -36,6 +46,11 @@ def main():
     for r in range(rounds):
         for name in libs:
             nat._lib = libs[name]
+            for k2, v2 in envs.items():      # clear the other runs' settings, apply this one's
+                if v2:
+                    os.environ.pop(v2.split("=")[0], None)
+            if envs.get(name):
+                os.environ[envs[name].split("=")[0]] = envs[name].split("=")[1]
             if hasattr(env, "_step_args"):
                 env._step_args = None            # cached function pointer of the previous library
             for i in range(100):
