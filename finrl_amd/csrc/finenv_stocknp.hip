@@ -455,6 +455,7 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
 #pragma unroll
             for (int i = 0; i < kMaxN; ++i) pr_[i] = *at(p.panel.price, pb + (unsigned)min(i, N - 1));
         }
+        NSTAMP(11);
 #pragma unroll
         for (int i = 0; i < kMaxN; ++i) {                                         // sells :112-119
             if (i >= N) continue;             // (continue, not break: keeps the loop fully unrollable)
@@ -474,6 +475,7 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
             cr[i] = ok ? 0.0f : cr[i];
             amt = ok ? amt_new : amt;
         }
+        NSTAMP(7);
         double xr[kMaxN];
 #pragma unroll
         for (int i = 0; i < kMaxN; ++i) {
@@ -481,6 +483,7 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
             const double x = __builtin_amdgcn_rcp(d);
             xr[i] = fma(fma(-d, x, 1.0), x, x);
         }
+        NSTAMP(12);
 #pragma unroll
         for (int i = 0; i < kMaxN; ++i) {                                         // buys :120-129
             if (i >= N) continue;
@@ -501,6 +504,7 @@ __global__ void __launch_bounds__(kWave *kWaves *(RESET_ONLY ? 1 : 2)) stocknp_k
             amt = ok ? amt_new : amt;
         }
         amount = mk(amt, FINENV_NT_F64);
+        NSTAMP(8);
         // books back to LDS and, in the same pass, this env's observation head (amount | stocks |
         // cool-downs) over the consumed action rows -- every lane has read its own action row above
         wave_sync();

@@ -35,6 +35,7 @@ def main():
     rel = a - a[:, :, 0].min(axis=1)[:, None, None]
     names = {0: "trader start", 1: "tile + state staged", 2: "sells + buys done", 3: "asset / reward",
              4: "heads filled", 5: "head chunks written", 6: "state stored",
+             11: "  (actions / prices in registers)", 7: "  (sells done)", 12: "  (reciprocals done)", 8: "  (buys done)",
              9: "streamer starts storing", 10: "streamer done"}
     print(f"stocknp E={E} waves={nw}; us since the first wave started (median; p95)")
     for k, n in names.items():
