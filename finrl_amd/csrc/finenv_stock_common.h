@@ -35,6 +35,8 @@ struct Params {
     int32_t desync_hint;  // envs may sit on different days (selects the kernel instantiation only)
     int32_t day0;
     uint32_t magicN;      // ceil(2^32 / N) for N >= 2 (exact f / N for f < 2^16)
+    int32_t block_base;   // first 64-env group of this launch (batches larger than one resident round of
+                          // blocks are stepped as several launches: launch_rounds below)
     int32_t diag;         // FINENV_DIAG builds only: phase-skip bitmask (timing experiments)
     unsigned long long *dbg;   // FINENV_DIAG builds only: [block][role][16] s_memrealtime stamps
 };
@@ -49,6 +51,46 @@ constexpr int kStepThreads = 2 * kWave;
 #endif
 
 using finenv_stock_impl::Params;
+
+// The step kernels are built for ONE resident round of blocks (every block in the same phase: traders
+// loading while nobody stores yet, streamers streaming while traders compute).  Handed more blocks than
+// fit at once, the hardware refills slots as blocks finish, phases mix -- traders' loads queue behind
+// other blocks' stores -- and the per-env cost rises by a third (DOW30: 65,536 envs 0.64 of the
+// roofline, 262,144 envs 0.47; profiles/r03_placement.md).  So a large batch is stepped as
+// ceil(blocks / round) launches of equal size on the caller's stream, each one resident round or less.
+// `fn(q, nblocks)` launches nblocks blocks with q.block_base set.
+template <typename Kernel, typename Launch>
+inline void launch_rounds(const Params &p, Kernel kernel, size_t lds_bytes, Launch fn)
+{
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+               prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    static int per_cu = 0;                       // (one static per kernel instantiation)
+    if (per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kernel), kStepThreads,
+                                                         lds_bytes) != hipSuccess || nb < 1)
+            nb = 1;
+        per_cu = nb;
+    }
+    const int blocks = (p.cfg.n_envs + kWave - 1) / kWave;
+    const int round = per_cu * cus;
+    Params q = p;
+    if (blocks <= round) {
+        q.block_base = 0;
+        fn(q, blocks);
+        return;
+    }
+    const int k = (blocks + round - 1) / round, chunk = (blocks + k - 1) / k;
+    for (int b = 0; b < blocks; b += chunk) {
+        q.block_base = b;
+        fn(q, blocks - b < chunk ? blocks - b : chunk);
+    }
+}
 
 #ifdef FINENV_DIAG
 #define DIAG(bit) (p.diag & (bit))

@@ -18,9 +18,12 @@ namespace np128 {
 template <bool TURB, bool STATS, int NT>
 int launch_step_wide(const Params &p, hipStream_t stream)
 {
-    const dim3 grid((unsigned)((p.cfg.n_envs + kWave - 1) / kWave)), block(kStepThreads);
-    hipLaunchKernelGGL((np128::stock_step_wide_kernel<TURB, STATS, NT>), grid, block,
-                       np128::WideGeom<NT>::kBytes, stream, p);
+    const dim3 block(kStepThreads);
+    launch_rounds(p, &np128::stock_step_wide_kernel<TURB, STATS, NT>, np128::WideGeom<NT>::kBytes,
+                  [&](const Params &q, int nb) {
+                      hipLaunchKernelGGL((np128::stock_step_wide_kernel<TURB, STATS, NT>), dim3((unsigned)nb), block,
+                                         np128::WideGeom<NT>::kBytes, stream, q);
+                  });
     return 0;
 }
 
@@ -30,7 +33,7 @@ int launch_step(const Params &p, int device, hipStream_t stream)
     if (p.cfg.n_tickers == 100 && p.cfg.hmax <= np128::WideGeom<100>::kMaxHmax)
         return launch_step_wide<TURB, STATS, 100>(p, stream);
     // one 128-thread block per 64 envs, dynamic LDS = kLdsStep
-    const dim3 grid((unsigned)((p.cfg.n_envs + kWave - 1) / kWave)), block(kStepThreads);
+    const dim3 block(kStepThreads);
     constexpr size_t lds = sizeof(float) * np128::kLdsStep;
     // > 64 KiB of dynamic LDS needs an explicit opt-in, once per device (a process may hold
     // handles on several GPUs)
@@ -45,7 +48,9 @@ int launch_step(const Params &p, int device, hipStream_t stream)
             attr_set_mask |= 1ull << dev;
         }
     }
-    hipLaunchKernelGGL((np128::stock_step_kernel<TURB, STATS>), grid, block, lds, stream, p);
+    launch_rounds(p, &np128::stock_step_kernel<TURB, STATS>, lds, [&](const Params &q, int nb) {
+        hipLaunchKernelGGL((np128::stock_step_kernel<TURB, STATS>), dim3((unsigned)nb), block, lds, stream, q);
+    });
     return 0;
 }
 }  // namespace

@@ -16,14 +16,18 @@ namespace np32 {
 template <bool TURB, bool STATS>
 int launch_step(const Params &p, int device, hipStream_t stream)
 {
-    // one 128-thread block per 64 envs, dynamic LDS = kLdsStep
-    const dim3 grid((unsigned)((p.cfg.n_envs + kWave - 1) / kWave)), block(kStepThreads);
+    // one 128-thread block per 64 envs, dynamic LDS = kLdsStep; one resident round of blocks per launch
+    const dim3 block(kStepThreads);
     constexpr size_t lds = sizeof(float) * np32::kLdsStep;
     (void)device;
     if (p.desync_hint)      // envs may sit on different days: the instantiation with the per-env fast paths
-        hipLaunchKernelGGL((np32::stock_step_kernel<TURB, STATS, true>), grid, block, lds, stream, p);
+        launch_rounds(p, &np32::stock_step_kernel<TURB, STATS, true>, lds, [&](const Params &q, int nb) {
+            hipLaunchKernelGGL((np32::stock_step_kernel<TURB, STATS, true>), dim3((unsigned)nb), block, lds, stream, q);
+        });
     else
-        hipLaunchKernelGGL((np32::stock_step_kernel<TURB, STATS, false>), grid, block, lds, stream, p);
+        launch_rounds(p, &np32::stock_step_kernel<TURB, STATS, false>, lds, [&](const Params &q, int nb) {
+            hipLaunchKernelGGL((np32::stock_step_kernel<TURB, STATS, false>), dim3((unsigned)nb), block, lds, stream, q);
+        });
     return 0;
 }
 }  // namespace

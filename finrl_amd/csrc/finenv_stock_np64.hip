@@ -17,10 +17,12 @@ template <bool TURB, bool STATS>
 int launch_step(const Params &p, int device, hipStream_t stream)
 {
     // one 128-thread block per 64 envs, dynamic LDS = kLdsStep
-    const dim3 grid((unsigned)((p.cfg.n_envs + kWave - 1) / kWave)), block(kStepThreads);
+    const dim3 block(kStepThreads);
     constexpr size_t lds = sizeof(float) * np64::kLdsStep;
     (void)device;
-    hipLaunchKernelGGL((np64::stock_step_kernel<TURB, STATS>), grid, block, lds, stream, p);
+    launch_rounds(p, &np64::stock_step_kernel<TURB, STATS>, lds, [&](const Params &q, int nb) {
+        hipLaunchKernelGGL((np64::stock_step_kernel<TURB, STATS>), dim3((unsigned)nb), block, lds, stream, q);
+    });
     return 0;
 }
 }  // namespace

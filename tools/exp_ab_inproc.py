@@ -30,7 +30,10 @@ def main():
     nat._lib, nat.LIB_PATH = libs["base"], base_path
     dev = torch.device("cuda", 0)
     E = 65536
-    if kind.startswith("crypto"):          # crypto32768 / crypto65536 / crypto131072 / crypto262144
+    if ":" in kind:                        # "<kind>:<envs>", e.g. n30:262144
+        kind, e_txt = kind.split(":")
+        E = int(e_txt)
+    if kind.startswith("crypto") and kind != "crypto":      # crypto32768 / crypto65536 / crypto131072 / crypto262144
         E = int(kind[6:])
     a = dict(env="crypto", tickers=30, turbulence_pct=None) if kind.startswith("crypto") else \
         dict(env="portfolio", tickers=30, turbulence_pct=None) if kind == "portfolio" else \
