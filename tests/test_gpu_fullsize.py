@@ -222,3 +222,50 @@ def test_fullsize_desynchronised_sampled_oracle(hint):
     np.testing.assert_array_equal(st["day"][sample], os_["day"])
     np.testing.assert_array_equal(st["cash"][sample], os_["cash"])
     np.testing.assert_array_equal(st["shares"][sample], os_["shares"])
+
+
+@pytest.mark.parametrize("N,E", [(30, 69_700), (100, 66_000), (50, 40_000)])
+def test_batches_larger_than_one_round_of_blocks(N, E):
+    """More 64-env groups than fit on the chip at once: the step is issued as several equal launches
+    (launch_rounds, finenv_stock_common.h), each with its own first group.  Every env of every round -- the
+    last group is a partial wave -- against the oracle on sampled envs, plus size-independent properties
+    over the whole batch, across an episode end."""
+    _need_gpu()
+    from finrl_amd import StockPanel
+    from finrl_amd.vec_env import VecStockTradingEnv
+    from oracle.stock import StockOracle
+    T, K = 9, 2
+    rng = np.random.default_rng(N + E)
+    close = 100 * np.exp(np.cumsum(rng.normal(0, 0.02, (T, N)), axis=0))
+    tech = rng.normal(0, 1, (T, K, N))
+    risk = np.abs(rng.normal(0, 30, T))
+    kw = dict(hmax=40, initial_amount=60_000, turbulence_threshold=45.0)
+    env = VecStockTradingEnv(StockPanel(close, tech, risk), E, **kw)
+    env.enable_terminal_obs()
+    sample = np.unique(np.concatenate([[0, 63, 64, E - 1, E - 2, E // 2, E // 2 + 1],
+                                       rng.choice(E, 250, replace=False)]))
+    # the groups around every round boundary a 2- / 3-round split of this batch could have
+    blocks = (E + 63) // 64
+    for k in (2, 3):
+        chunk = (blocks + k - 1) // k
+        for b in range(chunk, blocks, chunk):
+            sample = np.union1d(sample, [min(E - 1, 64 * b - 1), min(E - 1, 64 * b), min(E - 1, 64 * b + 63)])
+    orc = StockOracle(close, tech, risk, n_envs=len(sample), **kw)
+    np.testing.assert_array_equal(env.reset()[sample].cpu().numpy(), orc.reset().astype(np.float32))
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(E)
+    for s in range(2 * T + 1):
+        a = torch.rand(E, N, generator=gen, device="cuda") * 2 - 1
+        obs, rew, done, _ = env.step(a)
+        o_obs, o_rew, o_done, o_term = orc.vec_step(a[sample].cpu().numpy())
+        np.testing.assert_array_equal(obs[sample].cpu().numpy(), o_obs.astype(np.float32), err_msg=f"step {s}")
+        np.testing.assert_array_equal(rew[sample].cpu().numpy(), o_rew.astype(np.float32))
+        np.testing.assert_array_equal(done[sample].cpu().numpy().astype(bool), o_done)
+        # lock-step batch: every env is on the same day and finishes together
+        assert int(done.sum()) in (0, E) and len(torch.unique(env.state["day"])) == 1
+        if o_done.any():
+            np.testing.assert_array_equal(env.term_obs[sample].cpu().numpy(), o_term.astype(np.float32))
+    st, os_ = env.state_numpy(), orc.state()
+    np.testing.assert_array_equal(st["cash"][sample], os_["cash"])
+    np.testing.assert_array_equal(st["shares"][sample], os_["shares"])
+    assert int((env.state["holdings"] < 0).sum()) == 0 and float(env.state["cash"].min()) >= 0.0

@@ -142,3 +142,39 @@ def test_two_handles_on_two_streams_do_not_interfere():
     for env, ref in zip(inter, outs_serial):
         for k in ref:
             assert torch.equal(env.state[k], ref[k]), k
+
+
+def test_multi_round_step_under_graph_capture():
+    """A stock batch with more 64-env groups than one resident round (two launches per step) captured in a
+    hipGraph: the replay equals the eager run bit for bit (every launch of a step lands in the capture)."""
+    _need_gpu()
+    from finrl_amd import StockPanel
+    from finrl_amd.vec_env import VecStockTradingEnv
+    rng = np.random.default_rng(2)
+    T, N, K, E = 12, 30, 2, 70_000
+    close = 100 * np.exp(np.cumsum(rng.normal(0, 0.02, (T, N)), axis=0))
+    panel = StockPanel(close, rng.normal(0, 1, (T, K, N)), np.abs(rng.normal(0, 30, T)))
+    a_env = VecStockTradingEnv(panel, E, hmax=30, initial_amount=40_000)
+    b_env = VecStockTradingEnv(panel, E, hmax=30, initial_amount=40_000)
+    acts = [torch.rand(E, N, device="cuda") * 2 - 1 for _ in range(4)]
+    a_env.reset(); b_env.reset()
+    b_env.step(acts[0]); a_env.step(acts[0])          # first call outside the capture (occupancy query, caches)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        pass
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for t in range(1, 4):
+            b_env.step(acts[t])
+    # the capture did not execute anything: bring b to the state before the captured steps, then replay
+    for k, v in a_env.state.items():
+        b_env.state[k].copy_(v)
+    b_env.obs.copy_(a_env.obs)
+    for t in range(1, 4):
+        a_env.step(acts[t])
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(a_env.obs, b_env.obs) and torch.equal(a_env.reward, b_env.reward)
+    for k in a_env.state:
+        assert torch.equal(a_env.state[k], b_env.state[k]), k
