@@ -114,3 +114,32 @@ def test_stocknp_hip_matches_oracle_random_batch(cfg):
             np.testing.assert_array_equal(env.term_obs.cpu().numpy()[o_done], o_term[o_done])
     assert nd >= 2
     assert len(np.unique(env.state_numpy()["amount_tag"])) >= 1
+
+
+def test_stocknp_batch_larger_than_one_round():
+    """More blocks than fit on the chip at once (the hardware refills slots as blocks finish): sampled envs
+    from both ends, the middle and around block boundaries vs the oracle, across an episode end."""
+    _need_gpu()
+    from finrl_amd.vec_stocknp import VecStockTradingEnvNP
+    from oracle.stocknp import StockNpOracle
+    E, T, N, K = 70_100, 10, 30, 2
+    rng = np.random.default_rng(6)
+    price = 100 * np.exp(np.cumsum(rng.normal(0, 0.01, (T, N)), axis=0))
+    tech = rng.normal(0, 50, (T, N * K))
+    turb = np.abs(rng.normal(0, 60, T))
+    env = VecStockTradingEnvNP({"price_array": price, "tech_array": tech, "turbulence_array": turb,
+                                "if_train": False}, E)
+    sample = np.unique(np.concatenate([[0, 255, 256, E - 1, E - 70, 35_071, 35_072, 35_327, 35_328],
+                                       rng.choice(E, 200, replace=False)]))
+    orc = StockNpOracle(price, tech, turb, n_envs=len(sample))
+    np.testing.assert_array_equal(env.reset()[sample].cpu().numpy(), orc.reset())
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(9)
+    for s in range(2 * T):
+        a = torch.rand(E, N, generator=gen, device="cuda") * 2 - 1
+        obs, rew, done, _ = env.step(a)
+        o_obs, o_rew, o_done, _ = orc.vec_step(a[sample].cpu().numpy())
+        np.testing.assert_array_equal(obs[sample].cpu().numpy(), o_obs, err_msg=f"step {s}")
+        np.testing.assert_array_equal(rew[sample].cpu().numpy(), o_rew.astype(np.float32))
+        np.testing.assert_array_equal(done[sample].cpu().numpy().astype(bool), o_done)
+        assert int(done.sum()) in (0, E)
