@@ -626,6 +626,9 @@ def main(argv=None):
     import torch.distributed as dist
 
     selftest = args.env == "launcher-selftest"
+    # FINENV_BENCH_REHEARSAL=1: every rank on cuda:0 with gloo for the gather -- the N > 1 path with the real
+    # kernels on a one-GPU box (RCCL needs one GPU per rank); tests/test_gpu_bench_contract.py.  Never a result.
+    rehearsal = os.environ.get("FINENV_BENCH_REHEARSAL") == "1"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -634,12 +637,12 @@ def main(argv=None):
                          "run `bench.py --gpus N` without a torchrun environment (it launches them)")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if selftest:
+        if selftest or rehearsal:
             dist.init_process_group("gloo")
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cpu") if selftest else torch.device("cuda", local_rank)
+    dev = torch.device("cpu") if selftest else torch.device("cuda", 0 if rehearsal else local_rank)
     prewarm = args.prewarm if args.prewarm is not None else \
         (PREWARM_DEFAULT if args.warmup < 1024 else 0)
 
@@ -684,7 +687,8 @@ def main(argv=None):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64",
+            "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU, gloo)",
             "prewarm_launches": prewarm,
             "config": dict({"workload": work.workload, "envs_per_gpu": E,
                             "global_envs": world * E, "parallelism": f"env-shard x{world}"},

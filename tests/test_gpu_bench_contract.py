@@ -12,10 +12,11 @@ torch = pytest.importorskip("torch")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(*args):
+def _bench(*args, extra_env=None):
     if not torch.cuda.is_available():
         pytest.fail("no HIP device visible: GPU tests must run on the MI355X box")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(extra_env or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, cwd="/tmp",
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -64,3 +65,18 @@ def test_configs4_slice_line():
     _check_common(j, 64, 16)
     assert j["config"]["rollout_n_steps"] == 16 and "hipGraph" in j["config"]["launch"]
     assert "cpu_baseline" not in j
+
+
+def test_two_rank_rehearsal_of_the_scaling_command():
+    """`python bench.py --gpus 2` exactly as the driver would issue it for a scaling run, on this one-GPU box:
+    bench.py starts its own two ranks (child torch.distributed.run), each builds its shard with the real
+    kernels and the timed region gathers episode returns -- with every rank on cuda:0 and gloo instead of RCCL
+    (FINENV_BENCH_REHEARSAL=1).  Checks the plumbing and the accounting, not the speed."""
+    j = _bench("--gpus", "2", "--envs-per-gpu", "8192", "--steps", "40", "--warmup", "8", "--prewarm", "16",
+               "--no-cpu-baseline", extra_env={"FINENV_BENCH_REHEARSAL": "1"})
+    assert j["n_gpus"] == 2 and j["steps"] == 40 and j["scaling"] == "weak"
+    assert j["config"]["envs_per_gpu"] == 8192 and j["config"]["global_envs"] == 16384
+    assert j["config"]["parallelism"] == "env-shard x2"
+    assert j["rccl"]["world"] == 2 and j["rccl"]["gathers"] >= 1 and j["rccl"]["gathered"] == 16384
+    assert abs(j["value"] - 16384 * 40 / (j["ms_per_step"] * 1e-3 * 40)) / j["value"] < 1e-9
+    assert "REHEARSAL" in j["data"] and "cpu_baseline" not in j
